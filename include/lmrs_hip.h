@@ -1,0 +1,133 @@
+/*
+ * lmrs_hip.h — C ABI of the MI355X-native decode hot path for lm.rs models.
+ *
+ * This is the drop-in boundary: every entry point replaces one
+ * member of the public surface of `lmrs::transformer::Transformer`
+ * (reference src/transformer.rs) or one of the L2 free functions in
+ * src/functional.rs / src/quantization.rs.  The reference has no FFI of its own,
+ * so the signatures below are what a Rust `extern "C"` block would bind (the
+ * binding itself is shown in INTEGRATION.md).  Plain pointers and sizes only.
+ *
+ * The same prototypes, with the prefix `lmrs_ref_` instead of `lmrs_`, are
+ * implemented by the CPU oracle (oracle/lmrs_oracle.c).  The oracle is test
+ * infrastructure; nothing in this library calls it.
+ *
+ * Conventions
+ *   - every function returning int: 0 = ok, <0 = error (text via lmrs_last_error()).
+ *     The reference panics on error (assert!/expect); a Rust shim turns !=0 into panic!.
+ *   - a context is NOT thread-safe (reference: `&mut self`); several contexts may coexist.
+ *   - all host pointers are caller-owned unless stated.
+ */
+#ifndef LMRS_HIP_H
+#define LMRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lmrs_ctx lmrs_ctx;
+
+/* Mirror of TransformerArgs (reference src/transformer.rs:57-74), natural C layout
+ * (the on-disk struct is packed; see lmrs_create).  seq_len is already clamped to
+ * 8192 as the reference does (src/transformer.rs:158-160). */
+typedef struct lmrs_args {
+    uint32_t dim, hidden_dim, n_layers, n_heads, head_size, n_kv_heads, vocab_size, seq_len;
+    float    rms_norm_eps, rope_theta;
+    uint8_t  q_type;      /* 0 None, 1 Q8_0, 2 Q4_0      (src/quantization.rs:1-6)  */
+    uint8_t  model_type;  /* 0 GEMMA, 1 LLAMA, 2 PHI      (src/transformer.rs:50-55) */
+    uint8_t  multimodal;
+    uint8_t  _pad;
+    uint32_t group_size;
+} lmrs_args;
+
+enum { LMRS_Q_NONE = 0, LMRS_Q8_0 = 1, LMRS_Q4_0 = 2 };
+enum { LMRS_GEMMA = 0, LMRS_LLAMA = 1, LMRS_PHI = 2 };
+
+/* ---- Transformer::new  (src/transformer.rs:134-314) -------------------------------
+ * Parses an LMRS v4 image (`file`,`len` = the mmap the reference hands to
+ * Transformer::new), uploads the weights to HBM on HIP device `device`, allocates the
+ * KV cache and activation buffers there.  *bytes_consumed = offset of the first byte
+ * after the text model (what the reference returns as the second tuple element).
+ * The host image is not referenced after return. */
+int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx** out, size_t* bytes_consumed);
+
+/* Row-sharded variant: this process is shard `rank` of `world`
+ * (one process per GPU).  `nccl_unique_id` points at the 128-byte ncclUniqueId created
+ * by rank 0 and distributed by the host (e.g. torch.distributed broadcast); it may be
+ * NULL when world == 1.  Results are bit-identical to world == 1. */
+int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world,
+                        const void* nccl_unique_id, lmrs_ctx** out, size_t* bytes_consumed);
+
+/* Writes the 128-byte ncclUniqueId for lmrs_create_sharded (call on rank 0). */
+int lmrs_comm_unique_id(void* out128);
+
+/* Drop for Transformer (src/transformer.rs:688-712). */
+void lmrs_destroy(lmrs_ctx* ctx);
+
+/* `pub args` (src/transformer.rs:128). Pointer is valid for the life of ctx. */
+const lmrs_args* lmrs_get_args(const lmrs_ctx* ctx);
+
+/* ---- Transformer::forward  (src/transformer.rs:316-384) ---------------------------
+ * One decode step.  *logits points at ctx-owned pinned host memory holding
+ * vocab_size floats, valid (and mutable: the reference sampler scales them in place,
+ * src/sampler.rs:115-117) until the next call on this ctx. */
+int lmrs_forward(lmrs_ctx* ctx, uint32_t token, uint32_t pos, float** logits);
+
+/* Same step followed by Sampler::sample_argmax (src/sampler.rs:29-41: first index of the
+ * maximum) on the device; no logits leave HBM. */
+int lmrs_forward_argmax(lmrs_ctx* ctx, uint32_t token, uint32_t pos, uint32_t* next);
+
+/* ---- Transformer::get_embeddings  (src/transformer.rs:659-669) -------------------- */
+int lmrs_get_embeddings(const lmrs_ctx* ctx, const uint32_t* tokens, size_t n, float* out /* n*dim */);
+
+/* ---- Transformer::fill_kv_cache  (src/transformer.rs:672-684) ---------------------
+ * Runs all layers over `n` embeddings (n*dim floats, updated in place exactly as the
+ * reference mutates its argument) at positions curr_pos..curr_pos+n-1; no logits.
+ * *new_pos = curr_pos + n. */
+int lmrs_fill_kv_cache(lmrs_ctx* ctx, float* embeddings, uint32_t n, uint32_t curr_pos, uint32_t* new_pos);
+
+/* ---- the generation loop of src/bin/chat.rs:188-222 on token IDs, greedy ------------
+ * Feeds prompt[0..n_prompt) token by token starting at position start_pos (sampler
+ * output ignored while the prompt lasts, as chat.rs does), then n_new-1 further steps
+ * feeding back the argmax.  out_tokens[i] (i < n_new) = i-th generated token, i.e. the
+ * argmax after step n_prompt-1+i.  Runs device-resident: one host sync at the end.
+ * *seconds (optional) = wall time of the whole call's device work (HIP events). */
+int lmrs_generate_greedy(lmrs_ctx* ctx, const uint32_t* prompt, size_t n_prompt, uint32_t n_new,
+                         uint32_t start_pos, uint32_t* out_tokens, double* seconds);
+
+const char* lmrs_last_error(void);
+
+/* ---- L2 free functions, for unit parity (host pointers in and out) ------------------
+ * Each runs the SAME device kernel the decode path uses, on device `device`.          */
+/* functional.rs:173-214.  x: sl rows of n int8 + sl*n/gs scales; w: o*n int8 + o*n/gs scales. */
+int lmrs_op_matmul_q8(int device, float* xout, const int8_t* xq, const float* xs,
+                      const int8_t* wq, const float* ws, size_t n, size_t o, size_t gs, size_t sl);
+/* functional.rs:216-250 (decode form, sl = 1).  xq: n/2 bytes, wq: o*n/2 bytes. */
+int lmrs_op_matmul_q4(int device, float* xout, const uint8_t* xq, const float* xs,
+                      const uint8_t* wq, const float* ws, size_t n, size_t o, size_t gs);
+/* quantization.rs:44-67 */
+int lmrs_op_quantize(int device, int8_t* q, float* s, const float* x, size_t n, size_t gs);
+/* quantization.rs:69-95 */
+int lmrs_op_quantize_q4(int device, uint8_t* q, float* s, const float* x, size_t n, size_t gs);
+/* functional.rs:48-78 */
+int lmrs_op_rmsnorm(int device, float* o, const float* x, const float* weight, size_t size, float eps, int add_unit_offset);
+/* functional.rs:122-140 (in place) */
+int lmrs_op_softmax(int device, float* x, size_t n);
+/* f32::exp as used by softmax / SiLU: the device's bit-exact restatement of glibc expf. */
+int lmrs_op_expf(int device, float* y, const float* x, size_t n);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------
+ * Time `iters` back-to-back launches of the Q8_0 dequant-GEMV kernel on the weights of
+ * (layer, which) with HIP events on the context's stream.  which: 0 qkv, 1 wo, 2 w1w3,
+ * 3 w2, 4 classifier.  *bytes = algorithmic bytes (int8 + scales) one launch reads. */
+int lmrs_bench_gemv(lmrs_ctx* ctx, int which, int layer, int iters, double* avg_us, double* bytes);
+/* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos`. */
+int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMRS_HIP_H */

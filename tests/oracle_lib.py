@@ -1,0 +1,167 @@
+"""ctypes binding of the CPU oracle (oracle/liblmrs_oracle.so).  TEST INFRASTRUCTURE: imported only
+by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liblmrs_oracle.so")
+
+
+class Args(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("dim", "hidden_dim", "n_layers", "n_heads", "head_size", "n_kv_heads", "vocab_size", "seq_len")] + [
+        ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float), ("q_type", C.c_uint8), ("model_type", C.c_uint8),
+        ("multimodal", C.c_uint8), ("_pad", C.c_uint8), ("group_size", C.c_uint32)]
+
+
+def build_oracle(force: bool = False):
+    src = os.path.join(ORACLE_DIR, "lmrs_oracle.c")
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "liblmrs_oracle.so"], check=True)
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        vp, u32, sz, f32p = C.c_void_p, C.c_uint32, C.c_size_t, C.POINTER(C.c_float)
+        L.lmrs_ref_last_error.restype = C.c_char_p
+        L.lmrs_ref_create.argtypes = [vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.lmrs_ref_destroy.argtypes = [vp]
+        L.lmrs_ref_get_args.argtypes = [vp]; L.lmrs_ref_get_args.restype = C.POINTER(Args)
+        L.lmrs_ref_forward.argtypes = [vp, u32, u32, C.POINTER(f32p)]
+        L.lmrs_ref_forward_argmax.argtypes = [vp, u32, u32, C.POINTER(u32)]
+        L.lmrs_ref_get_embeddings.argtypes = [vp, vp, sz, vp]
+        L.lmrs_ref_fill_kv_cache.argtypes = [vp, vp, u32, u32, C.POINTER(u32)]
+        L.lmrs_ref_generate_greedy.argtypes = [vp, vp, sz, u32, u32, vp, C.POINTER(C.c_double)]
+        L.lmrs_ref_argmax.argtypes = [vp, sz]; L.lmrs_ref_argmax.restype = u32
+        L.lmrs_ref_threads.restype = C.c_int
+        L.lmrs_ref_kv.argtypes = [vp, C.c_int, u32, u32]; L.lmrs_ref_kv.restype = f32p
+        L.lmrs_ref_op_rmsnorm.argtypes = [vp, vp, vp, sz, C.c_float, C.c_int]; L.lmrs_ref_op_rmsnorm.restype = None
+        L.lmrs_ref_op_softmax.argtypes = [vp, sz]; L.lmrs_ref_op_softmax.restype = None
+        L.lmrs_ref_op_matmul_q8.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]; L.lmrs_ref_op_matmul_q8.restype = None
+        L.lmrs_ref_op_matmul_q4.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz]; L.lmrs_ref_op_matmul_q4.restype = None
+        L.lmrs_ref_op_quantize.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize.restype = None
+        L.lmrs_ref_op_quantize_q4.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize_q4.restype = None
+        L.lmrs_ref_op_expf.argtypes = [C.c_float]; L.lmrs_ref_op_expf.restype = C.c_float
+        L.lmrs_ref_rope_terms.argtypes = [C.POINTER(Args), u32, u32, f32p, f32p]; L.lmrs_ref_rope_terms.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Mirror of lmrs::transformer::Transformer over the oracle."""
+
+    def __init__(self, image: np.ndarray):
+        image = np.ascontiguousarray(image, np.uint8)
+        h, used = C.c_void_p(), C.c_size_t()
+        if lib().lmrs_ref_create(_p(image), image.size, 0, C.byref(h), C.byref(used)):
+            raise RuntimeError(lib().lmrs_ref_last_error().decode())
+        self.h, self.bytes_consumed = h, used.value
+        self.args = lib().lmrs_ref_get_args(h).contents
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lmrs_ref_destroy(self.h); self.h = None
+
+    def _chk(self, rc):
+        if rc:
+            raise RuntimeError(lib().lmrs_ref_last_error().decode())
+
+    def forward(self, token: int, pos: int) -> np.ndarray:
+        p = C.POINTER(C.c_float)()
+        self._chk(lib().lmrs_ref_forward(self.h, token, pos, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(self.args.vocab_size,))
+
+    def forward_argmax(self, token: int, pos: int) -> int:
+        n = C.c_uint32()
+        self._chk(lib().lmrs_ref_forward_argmax(self.h, token, pos, C.byref(n)))
+        return n.value
+
+    def get_embeddings(self, tokens) -> np.ndarray:
+        t = np.ascontiguousarray(tokens, np.uint32)
+        out = np.empty(t.size * self.args.dim, np.float32)
+        self._chk(lib().lmrs_ref_get_embeddings(self.h, _p(t), t.size, _p(out)))
+        return out
+
+    def fill_kv_cache(self, embeddings: np.ndarray, curr_pos: int) -> int:
+        assert embeddings.dtype == np.float32 and embeddings.flags.c_contiguous
+        n = embeddings.size // self.args.dim
+        newp = C.c_uint32()
+        self._chk(lib().lmrs_ref_fill_kv_cache(self.h, _p(embeddings), n, curr_pos, C.byref(newp)))
+        return newp.value
+
+    def generate_greedy(self, prompt, n_new: int, start_pos: int = 0, timing: bool = False):
+        pr = np.ascontiguousarray(prompt, np.uint32)
+        out = np.zeros(n_new, np.uint32)
+        sec = C.c_double()
+        self._chk(lib().lmrs_ref_generate_greedy(self.h, _p(pr), pr.size, n_new, start_pos, _p(out), C.byref(sec)))
+        return (out, sec.value) if timing else out
+
+    def kv_row(self, which: int, layer: int, pos: int) -> np.ndarray:
+        kv = self.args.n_kv_heads * self.args.head_size
+        return np.ctypeslib.as_array(lib().lmrs_ref_kv(self.h, which, layer, pos), shape=(kv,)).copy()
+
+
+# ---- free functions (functional.rs / quantization.rs)
+def rmsnorm(x, w, eps, add_unit_offset=False):
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+    o = np.empty_like(x)
+    lib().lmrs_ref_op_rmsnorm(_p(o), _p(x), _p(w), x.size, eps, int(add_unit_offset))
+    return o
+
+
+def softmax(x):
+    x = np.array(x, np.float32, copy=True)
+    lib().lmrs_ref_op_softmax(_p(x), x.size)
+    return x
+
+
+def quantize(x, gs=128):
+    x = np.ascontiguousarray(x, np.float32)
+    q = np.empty(x.size, np.int8); s = np.empty(x.size // gs, np.float32)
+    lib().lmrs_ref_op_quantize(_p(q), _p(s), _p(x), x.size, gs)
+    return q, s
+
+
+def quantize_q4(x, gs=128):
+    x = np.ascontiguousarray(x, np.float32)
+    q = np.empty(x.size // 2, np.uint8); s = np.empty(x.size // gs, np.float32)
+    lib().lmrs_ref_op_quantize_q4(_p(q), _p(s), _p(x), x.size, gs)
+    return q, s
+
+
+def matmul_q8(xq, xs, wq, ws, n, o, gs=128, sl=1):
+    out = np.zeros(sl * o, np.float32)
+    lib().lmrs_ref_op_matmul_q8(_p(out), _p(np.ascontiguousarray(xq, np.int8)), _p(np.ascontiguousarray(xs, np.float32)),
+                                _p(np.ascontiguousarray(wq, np.int8)), _p(np.ascontiguousarray(ws, np.float32)), n, o, gs, sl)
+    return out
+
+
+def matmul_q4(xq, xs, wq, ws, n, o, gs=128):
+    out = np.zeros(o, np.float32)
+    lib().lmrs_ref_op_matmul_q4(_p(out), _p(np.ascontiguousarray(xq, np.uint8)), _p(np.ascontiguousarray(xs, np.float32)),
+                                _p(np.ascontiguousarray(wq, np.uint8)), _p(np.ascontiguousarray(ws, np.float32)), n, o, gs)
+    return out
+
+
+def expf(x: float) -> float:
+    return lib().lmrs_ref_op_expf(float(x))
+
+
+def threads() -> int:
+    return lib().lmrs_ref_threads()

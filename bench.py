@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — decode tok/s + %HBM-roofline, Llama-3.2-1B Q8_0 greedy decode on MI355X (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one decode step (one token through the whole hot path: embedding row, 16 decoder layers,
+classifier, argmax).  Workload (config.workload): BASELINE.json configs[1] — synthetic LMRS image with the
+real Llama-3.2-1B shapes (tools/synth_lmrs.py, seed 1234, weights quantised with the reference's Q8_0
+quantiser), a 16-token synthetic prompt (= the W warm-up steps by default) and then K greedy tokens.
+Weights, KV cache and every activation are resident in HBM when the timed region starts; token ids never
+leave the device between steps.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      the dominant kernel (the fused Q8_0 dequant-GEMV, lmrs::gemv_kernel<...>): algorithmic bytes
+                (int8 weights + f32 group scales) of one decode step's 81 GEMV launches / their summed
+                durations, each measured live with HIP events on the library's stream (lmrs_bench_gemv),
+                against the 8 TB/s HBM3E peak.  `path` carries the whole-step figure (SURVEY.md §8d bytes
+                per token / measured time per token).
+  cpu_baseline  the CPU oracle (a C port of the reference's arithmetic, oracle/lmrs_oracle.c; the Rust
+                reference itself cannot be built here) timed on this box's host cores on the same prompt.
+                The same run is the parity gate: the K token ids must be identical.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="llama-3.2-1b")
+    ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1: same as the GPU run, 0: skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def device_sync():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+        else:
+            hip.hipDeviceSynchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import lmrs_amd
+    from tools import synth_lmrs as S
+
+    cfg = S.CONFIGS[args.model]
+    K, W = args.steps, max(1, args.warmup)
+    if W + K > 8192:
+        raise SystemExit("warmup + steps must fit the 8192-position KV cache")
+    t0 = time.time()
+    img = S.build_image(cfg, S.Q8_0, seed=1234)
+    prompt = S.prompt_tokens(cfg, W, 1234)
+    t_build = time.time() - t0
+
+    # N > 1: this round has no row-sharded path yet -> N independent replicas of the same decode stream.
+    model = lmrs_amd.Transformer(img, device=local_rank)
+
+    # ---- warm-up: the W prompt tokens (token by token, as the reference feeds prompts), untimed
+    first = model.generate_greedy(prompt, 1)
+    device_sync(); barrier()
+    # ---- timed: exactly K decode steps at positions W .. W+K-1
+    t1 = time.perf_counter()
+    toks, dev_sec = model.generate_greedy(first, K, start_pos=W, timing=True)
+    device_sync(); barrier()
+    t2 = time.perf_counter()
+    elapsed = t2 - t1
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gen = np.concatenate([first, toks])[: K + 1]          # token ids produced after positions W-1 .. W+K-1
+
+    out = None
+    if rank == 0:
+        tok_s = world * K / elapsed
+        # whole-path bytes over the timed positions
+        path_bytes = sum(model.step_info(p)[1] for p in range(W, W + K))
+        n_launch = model.step_info(W)[0]
+        # ---- dominant kernel: per-shape live timing with HIP events
+        iters = 5
+        res = model.bench_gemv(iters)
+        per, tot_us, tot_b, n_gemv = {}, 0.0, 0.0, 0
+        for name, (us, b, n) in res.items():
+            per[name] = {"us": round(us / n, 3), "MB": round(b / n / 1e6, 3), "GBps": round(b / us / 1e3, 1), "launches_per_step": n // iters}
+            tot_us += us / iters; tot_b += b / iters; n_gemv += n // iters
+        achieved = tot_b / tot_us / 1e3            # GB/s
+        roofline = {
+            "bound": "hbm", "kernel": "lmrs::gemv_kernel (fused Q8_0 dequant-GEMV, all shapes of one step)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": None,
+            "bytes_per_launch_avg": round(tot_b / n_gemv), "avg_launch_us": round(tot_us / n_gemv, 3), "launches_per_step": n_gemv,
+            "per_shape": per,
+            "path": {"bytes_per_step": round(path_bytes / K), "us_per_step": round(elapsed / K * 1e6, 2),
+                     "achieved": round(path_bytes / elapsed / 1e9, 1), "frac": round(path_bytes / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
+                     "kernel_launches_per_step": n_launch, "device_event_us_per_step": round(dev_sec / K * 1e6, 2)},
+        }
+        # ---- CPU baseline + parity gate
+        cpu = None; parity = None
+        cpu_steps = K if args.cpu_steps < 0 else args.cpu_steps
+        if cpu_steps > 0:
+            import oracle_lib as O
+            if args.cpu_threads > 0:
+                os.environ["LMRS_REF_THREADS"] = str(args.cpu_threads)
+            orc = O.Oracle(img)
+            n_new = min(cpu_steps, K) + 1
+            ref, sec = orc.generate_greedy(prompt, n_new, timing=True)
+            steps_run = W + n_new - 1
+            cpu = {"value": round(steps_run / sec, 2), "unit": "tok/s", "cores": O.threads(), "kind": "port",
+                   "sample": f"same image and prompt: {W} prompt + {n_new - 1} greedy steps in {sec:.2f}s, OpenMP over rows/heads"}
+            parity = {"tokens_compared": int(n_new), "tokens_equal": bool((ref == gen[:n_new]).all())}
+        out = {
+            "metric": "decode tok/s + %HBM-roofline, Llama-3.2-1B Q8_0 @1/2/4/8 MI355X vs CPU ref",
+            "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} Q8_0 (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (row-sharded path not built yet)",
+                       "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

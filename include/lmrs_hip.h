@@ -120,10 +120,12 @@ int lmrs_op_softmax(int device, float* x, size_t n);
 int lmrs_op_expf(int device, float* y, const float* x, size_t n);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------
- * Time `iters` back-to-back launches of the Q8_0 dequant-GEMV kernel on the weights of
- * (layer, which) with HIP events on the context's stream.  which: 0 qkv, 1 wo, 2 w1w3,
- * 3 w2, 4 classifier.  *bytes = algorithmic bytes (int8 + scales) one launch reads. */
-int lmrs_bench_gemv(lmrs_ctx* ctx, int which, int layer, int iters, double* avg_us, double* bytes);
+ * Runs, `iters` times, the dequant-GEMV launches of ONE decode step in step order (per layer: qkv, wo,
+ * w1w3, w2; then the classifier) so the weight stream is the real one, each launch bracketed by HIP events
+ * on the context's stream.  Index k of the outputs: 0 qkv, 1 wo, 2 w1w3, 3 w2, 4 classifier;
+ * us5[k] = summed duration (microseconds), bytes5[k] = summed algorithmic bytes (int8 + f32 scales),
+ * count5[k] = launches.  Activations hold garbage afterwards; weights and older KV rows are untouched. */
+int lmrs_bench_gemv(lmrs_ctx* ctx, int iters, double* us5, double* bytes5, int* count5);
 /* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos`. */
 int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);
 

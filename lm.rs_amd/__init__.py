@@ -1,0 +1,217 @@
+"""lm.rs_amd — MI355X-native decode hot path for lm.rs models (host-side mirror, Python flavour).
+
+`Transformer` mirrors the public surface of `lmrs::transformer::Transformer`
+(reference src/transformer.rs:127-131, :134, :316, :659, :672) over the C ABI of
+`liblmrs_hip.so` (include/lmrs_hip.h).  There is NO CPU fallback: if the HIP library is
+missing or no GPU is visible, construction raises.
+
+The directory name contains a dot, so import it through the repo-root shim:  `import lmrs_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmrs_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+GEMMA, LLAMA, PHI = 0, 1, 2
+Q_NONE, Q8_0, Q4_0 = 0, 1, 2
+
+# every symbol include/lmrs_hip.h declares (tests/test_abi.py checks the header against this list)
+EXPORTS = [
+    "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
+    "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
+    "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info",
+]
+
+
+class TransformerArgs(C.Structure):
+    """lmrs_args / TransformerArgs (src/transformer.rs:57-74)."""
+    _fields_ = [(n, C.c_uint32) for n in ("dim", "hidden_dim", "n_layers", "n_heads", "head_size", "n_kv_heads", "vocab_size", "seq_len")] + [
+        ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float), ("q_type", C.c_uint8), ("model_type", C.c_uint8),
+        ("multimodal", C.c_uint8), ("_pad", C.c_uint8), ("group_size", C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    """Compile liblmrs_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "lmrs_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-s", "-j4", "-C", CSRC], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is mandatory; there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, sz, f32p = C.c_void_p, C.c_uint32, C.c_size_t, C.POINTER(C.c_float)
+        L.lmrs_last_error.restype = C.c_char_p
+        L.lmrs_create.argtypes = [vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.lmrs_create_sharded.argtypes = [vp, sz, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp), C.POINTER(sz)]
+        L.lmrs_comm_unique_id.argtypes = [vp]
+        L.lmrs_destroy.argtypes = [vp]; L.lmrs_destroy.restype = None
+        L.lmrs_get_args.argtypes = [vp]; L.lmrs_get_args.restype = C.POINTER(TransformerArgs)
+        L.lmrs_forward.argtypes = [vp, u32, u32, C.POINTER(f32p)]
+        L.lmrs_forward_argmax.argtypes = [vp, u32, u32, C.POINTER(u32)]
+        L.lmrs_get_embeddings.argtypes = [vp, vp, sz, vp]
+        L.lmrs_fill_kv_cache.argtypes = [vp, vp, u32, u32, C.POINTER(u32)]
+        L.lmrs_generate_greedy.argtypes = [vp, vp, sz, u32, u32, vp, C.POINTER(C.c_double)]
+        L.lmrs_op_matmul_q8.argtypes = [C.c_int, vp, vp, vp, vp, vp, sz, sz, sz, sz]
+        L.lmrs_op_matmul_q4.argtypes = [C.c_int, vp, vp, vp, vp, vp, sz, sz, sz]
+        L.lmrs_op_quantize.argtypes = [C.c_int, vp, vp, vp, sz, sz]
+        L.lmrs_op_quantize_q4.argtypes = [C.c_int, vp, vp, vp, sz, sz]
+        L.lmrs_op_rmsnorm.argtypes = [C.c_int, vp, vp, vp, sz, C.c_float, C.c_int]
+        L.lmrs_op_softmax.argtypes = [C.c_int, vp, sz]
+        L.lmrs_op_expf.argtypes = [C.c_int, vp, vp, sz]
+        L.lmrs_bench_gemv.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.lmrs_step_info.argtypes = [vp, u32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+class LmrsError(RuntimeError):
+    """The reference panics (assert!/expect); the C ABI returns a status and we raise."""
+
+
+def _chk(rc):
+    if rc:
+        raise LmrsError(lib().lmrs_last_error().decode())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Transformer:
+    """Drop-in for lmrs::transformer::Transformer on one MI355X.
+
+    Transformer(data) -> like Transformer::new(&mmap): `data` is the LMRS image (bytes-like /
+    numpy uint8 / np.memmap).  `.bytes_consumed` is the second element of the reference's tuple.
+    """
+
+    def __init__(self, data, device: int = 0, rank: int = 0, world: int = 1, unique_id: bytes | None = None):
+        image = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8)
+        h, used = C.c_void_p(), C.c_size_t()
+        if world == 1:
+            _chk(lib().lmrs_create(_p(image), image.size, device, C.byref(h), C.byref(used)))
+        else:
+            uid = C.create_string_buffer(unique_id, 128) if unique_id else None
+            _chk(lib().lmrs_create_sharded(_p(image), image.size, device, rank, world, uid, C.byref(h), C.byref(used)))
+        self._h = h
+        self.bytes_consumed = used.value
+        self.args = lib().lmrs_get_args(h).contents
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lmrs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def forward(self, token: int, pos: int) -> np.ndarray:
+        """-> logits view (vocab_size f32, pinned host memory owned by the model, valid until the next call)."""
+        p = C.POINTER(C.c_float)()
+        _chk(lib().lmrs_forward(self._h, token, pos, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(self.args.vocab_size,))
+
+    def forward_argmax(self, token: int, pos: int) -> int:
+        n = C.c_uint32()
+        _chk(lib().lmrs_forward_argmax(self._h, token, pos, C.byref(n)))
+        return n.value
+
+    def get_embeddings(self, tokens) -> np.ndarray:
+        t = np.ascontiguousarray(tokens, np.uint32)
+        out = np.empty(t.size * self.args.dim, np.float32)
+        _chk(lib().lmrs_get_embeddings(self._h, _p(t), t.size, _p(out)))
+        return out
+
+    def fill_kv_cache(self, embeddings: np.ndarray, curr_pos: int) -> int:
+        if embeddings.dtype != np.float32 or not embeddings.flags.c_contiguous or embeddings.size % self.args.dim:
+            raise LmrsError("embeddings must be a contiguous float32 array of n*dim elements")
+        newp = C.c_uint32()
+        _chk(lib().lmrs_fill_kv_cache(self._h, _p(embeddings), embeddings.size // self.args.dim, curr_pos, C.byref(newp)))
+        return newp.value
+
+    def generate_greedy(self, prompt, n_new: int, start_pos: int = 0, timing: bool = False):
+        """chat.rs:188-222 on token IDs: returns the n_new greedy tokens (and device seconds if timing)."""
+        pr = np.ascontiguousarray(prompt, np.uint32)
+        out = np.zeros(n_new, np.uint32)
+        sec = C.c_double()
+        _chk(lib().lmrs_generate_greedy(self._h, _p(pr), pr.size, n_new, start_pos, _p(out), C.byref(sec)))
+        return (out, sec.value) if timing else out
+
+    # ---- measurement hooks
+    def bench_gemv(self, iters: int = 5):
+        """-> {shape: (sum_us, sum_bytes, launches)} over `iters` GEMV-only passes of one decode step."""
+        us, b, n = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int * 5)()
+        _chk(lib().lmrs_bench_gemv(self._h, iters, us, b, n))
+        names = ["qkv", "wo", "w1w3", "w2", "classifier"]
+        return {names[k]: (us[k], b[k], n[k]) for k in range(5)}
+
+    def step_info(self, pos: int):
+        n, b = C.c_int(), C.c_double()
+        _chk(lib().lmrs_step_info(self._h, pos, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
+
+# ---- free functions (functional.rs / quantization.rs), each on the device kernels
+def matmul_q8(xq, xs, wq, ws, n, o, gs=128, sl=1, device=0):
+    out = np.zeros(sl * o, np.float32)
+    _chk(lib().lmrs_op_matmul_q8(device, _p(out), _p(np.ascontiguousarray(xq, np.int8)), _p(np.ascontiguousarray(xs, np.float32)),
+                                 _p(np.ascontiguousarray(wq, np.int8)), _p(np.ascontiguousarray(ws, np.float32)), n, o, gs, sl))
+    return out
+
+
+def matmul_q4(xq, xs, wq, ws, n, o, gs=128, device=0):
+    out = np.zeros(o, np.float32)
+    _chk(lib().lmrs_op_matmul_q4(device, _p(out), _p(np.ascontiguousarray(xq, np.uint8)), _p(np.ascontiguousarray(xs, np.float32)),
+                                 _p(np.ascontiguousarray(wq, np.uint8)), _p(np.ascontiguousarray(ws, np.float32)), n, o, gs))
+    return out
+
+
+def quantize(x, gs=128, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    q = np.empty(x.size, np.int8); s = np.empty(x.size // gs, np.float32)
+    _chk(lib().lmrs_op_quantize(device, _p(q), _p(s), _p(x), x.size, gs))
+    return q, s
+
+
+def quantize_q4(x, gs=128, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    q = np.empty(x.size // 2, np.uint8); s = np.empty(x.size // gs, np.float32)
+    _chk(lib().lmrs_op_quantize_q4(device, _p(q), _p(s), _p(x), x.size, gs))
+    return q, s
+
+
+def rmsnorm(x, w, eps, add_unit_offset=False, device=0):
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+    o = np.empty_like(x)
+    _chk(lib().lmrs_op_rmsnorm(device, _p(o), _p(x), _p(w), x.size, eps, int(add_unit_offset)))
+    return o
+
+
+def softmax(x, device=0):
+    x = np.array(x, np.float32, copy=True)
+    _chk(lib().lmrs_op_softmax(device, _p(x), x.size))
+    return x
+
+
+def expf(x, device=0):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    _chk(lib().lmrs_op_expf(device, _p(y), _p(x), x.size))
+    return y

@@ -1,0 +1,632 @@
+// lmrs_api.hip — host side of the MI355X decode path and its C ABI (include/lmrs_hip.h).
+//
+// Mirrors lmrs::transformer::Transformer (reference src/transformer.rs): `new` (:134-314) becomes
+// lmrs_create (parse LMRS, upload weights to HBM, allocate KV cache + activations), `forward`
+// (:316-384) becomes one replay of a captured hipGraph (embedding -> n_layers x 5 fused kernels ->
+// classifier -> argmax), `get_embeddings` (:659-669) and `fill_kv_cache` (:672-684) likewise.
+//
+// HBM layout (all 256-byte aligned inside one arena):
+//   per layer  Wqkv  [(att+2kv) x dim] int8 (wq|wk|wv rows concatenated)  + scales [(att+2kv) x dim/128] f32
+//              Wo    [dim x att]                                          + scales
+//              W13   [2*hidden x dim], rows interleaved 2i = w1 (gate) row i, 2i+1 = w3 (up) row i
+//              W2    [dim x hidden]
+//              rms weights f32[dim] (att, post_att, and for Gemma pre_ffn, post_ffn)
+//   embedding / classifier table [vocab x dim] (+ Phi lm_head), rms_final
+//   KV cache   2 x [n_layers][seq_len][kv_dim] f32  (same layout as the reference, transformer.rs:302-303,413)
+//   RoPE table [seq_len][head/2] (fcr, fci) built on the host with libm (transformer.rs:446-482)
+//   activations x[dim], q[att], k_raw[kv], att_out[att], h[hidden], logits[vocab], argmax partials,
+//   tokens[seq_len+1], DevState
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lmrs_hip.h"
+#include "lmrs_format.h"
+#include "lmrs_kernels.h"
+
+using namespace lmrs;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+#define HIP_OK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+extern "C" const char* lmrs_last_error(void) { return g_err.c_str(); }
+
+namespace {
+
+struct DevLayer {
+    const void *wqkv, *wo, *w13, *w2;
+    const float *sqkv, *so, *s13, *s2;
+    const float *rms_att, *rms_post_att, *rms_pre_ffn, *rms_post_ffn;
+};
+
+}  // namespace
+
+struct lmrs_ctx {
+    lmrs_args args{};
+    Layout lay;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
+    std::vector<DevLayer> layers;
+    const void *emb_q = nullptr, *cls_q = nullptr; const float *emb_s = nullptr, *cls_s = nullptr, *rms_final = nullptr;
+    float *x = nullptr, *q = nullptr, *k_raw = nullptr, *att_out = nullptr, *h = nullptr, *logits = nullptr;
+    float *part_val = nullptr; int* part_idx = nullptr;
+    float *k_cache = nullptr, *v_cache = nullptr, *rope = nullptr;
+    float* stage = nullptr; size_t stage_floats = 0;        // device staging for fill_kv_cache / get_embeddings
+    uint32_t* tokens = nullptr; DevState* st = nullptr;
+    // pinned host
+    float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
+    hipGraphExec_t g_step = nullptr, g_layers = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int att_dim = 0, kv_dim = 0, cls_grid = 0;
+    bool q4 = false;
+
+    template <class T> T* alloc(size_t count) {
+        size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+        if (arena_used + bytes > arena_bytes) return nullptr;
+        T* p = reinterpret_cast<T*>(arena + arena_used); arena_used += bytes; return p;
+    }
+};
+
+namespace {
+
+__global__ void advance_pos_kernel(DevState* st) { st->pos += 1; st->step_count += 1; }
+
+size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// RoPE terms, transformer.rs:446-482 (libm powf/cosf/sinf/logf exactly where the reference calls them).
+void rope_terms(const lmrs_args& a, uint32_t p, uint32_t j, float* fcr, float* fci) {
+    static const double short_factor[48] = {   // transformer.rs:473
+        1.08, 1.1, 1.1300000000000001, 1.2800000000000002, 1.3100000000000003, 1.4500000000000004, 1.4500000000000004,
+        1.9500000000000008, 2.030000000000001, 2.4299999999999926, 2.5699999999999896, 2.9499999999999815, 3.729999999999965,
+        3.869999999999962, 4.189999999999955, 4.43999999999995, 4.6399999999999455, 4.979999999999938, 5.159999999999934,
+        5.279999999999932, 5.759999999999922, 5.889999999999919, 5.889999999999919, 5.969999999999917, 6.089999999999915,
+        6.2799999999999105, 6.7699999999999, 6.8899999999998975, 7.109999999999893, 7.129999999999892, 7.179999999999891,
+        7.289999999999889, 7.339999999999888, 7.559999999999883, 7.619999999999882, 7.69999999999988, 7.879999999999876,
+        7.879999999999876, 7.879999999999876, 7.939999999999875, 7.949999999999875, 7.979999999999874, 8.19999999999987,
+        8.439999999999864, 8.469999999999864, 8.589999999999861, 8.809999999999857, 8.999999999999853};
+    const uint32_t head_dim = j * 2;
+    float freq = 1.0f / powf(a.rope_theta, (float)head_dim / (float)a.head_size);
+    float scaling_factor = 1.0f;
+    if (a.model_type == LMRS_LLAMA) {                          // hard-coded Llama-3 scaling
+        const float wavelen = (2.0f * 3.14159265358979323846f) / freq;
+        const float factor = 32.0f, low_freq_factor = 1.0f, high_freq_factor = 4.0f, old_context_len = 8192.0f;
+        const float low_freq_wavelen = old_context_len / low_freq_factor;
+        const float high_freq_wavelen = old_context_len / high_freq_factor;
+        if (wavelen > low_freq_wavelen) freq = freq / factor;
+        else if (wavelen <= low_freq_wavelen && wavelen >= high_freq_wavelen) {
+            const float smooth_factor = (old_context_len / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor);
+            freq = (1.0f - smooth_factor) * freq / factor + smooth_factor * freq;
+        }
+    }
+    if (a.model_type == LMRS_PHI) {                            // LongRoPE short factors + long magnitude
+        freq = freq * (float)(1.0 / short_factor[j % 48]);
+        const float scale = 131072.0f / 4096.0f;
+        scaling_factor = sqrtf(1.0f + logf(scale) / logf(4096.0f));
+    }
+    const float val = (float)p * freq;
+    *fcr = cosf(val) * scaling_factor;
+    *fci = sinf(val) * scaling_factor;
+}
+
+// one decoder layer (transformer.rs:388-657) as 5 fused launches
+int enqueue_layer(lmrs_ctx* c, int l) {
+    const lmrs_args& a = c->args;
+    const DevLayer& L = c->layers[l];
+    const bool gemma = a.model_type == LMRS_GEMMA;
+    GemvArgs g{};
+    g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = gemma; g.st = c->st;
+    // 1. rmsnorm + quantize | Wqkv | q, raw k, v -> cache            (:409-431)
+    g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
+    g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
+    g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
+    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_QKV, c->stream));
+    // 2. RoPE + attention                                               (:443-544)
+    AttnArgs t{};
+    t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->att_out;
+    t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.seq_len = a.seq_len; t.layer = l;
+    t.gemma = gemma; t.st = c->st;
+    HIP_OK(launch_attention(t, c->stream));
+    // 3. quantize | Wo | x += ...                                       (:550-576)
+    g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = c->x;
+    HIP_OK(launch_gemv(g, PRO_QUANT, EPI_RESID, c->stream));
+    // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
+    g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h;
+    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_SWIGLU, c->stream));
+    // 5. quantize | W2 | x += ...                                       (:630-654)
+    g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = c->x;
+    HIP_OK(launch_gemv(g, PRO_QUANT, EPI_RESID, c->stream));
+    return 0;
+}
+
+GemvArgs cls_args(lmrs_ctx* c) {
+    const lmrs_args& a = c->args;
+    GemvArgs g{};
+    g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = a.model_type == LMRS_GEMMA; g.st = c->st;
+    g.wq = c->cls_q; g.ws = c->cls_s; g.n = a.dim; g.o = a.vocab_size; g.xin = c->x; g.rms_w = c->rms_final;
+    g.out = c->logits; g.part_val = c->part_val; g.part_idx = c->part_idx;
+    g.softcap_rows = a.model_type == LMRS_GEMMA ? (int)a.dim : 0;
+    return g;
+}
+
+int enqueue_step(lmrs_ctx* c) {
+    const lmrs_args& a = c->args;
+    EmbedArgs e{};
+    e.emb_q = c->emb_q; e.emb_s = c->emb_s; e.q4 = c->q4; e.tokens = c->tokens; e.x = c->x; e.dim = a.dim;
+    e.do_scale = a.model_type == LMRS_GEMMA; e.scale = sqrtf((float)a.dim); e.st = c->st;
+    HIP_OK(launch_embed(e, c->stream));
+    for (uint32_t l = 0; l < a.n_layers; ++l) if (enqueue_layer(c, (int)l)) return -1;
+    GemvArgs g = cls_args(c);                                   // final rmsnorm + quantize | classifier | argmax partials (:341-381)
+    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
+    ArgmaxArgs m{};
+    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st;
+    HIP_OK(launch_argmax_final(m, c->stream));
+    return 0;
+}
+
+int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out) {
+    hipGraph_t graph = nullptr;
+    HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    if (full) rc = enqueue_step(c);
+    else {
+        for (uint32_t l = 0; l < c->args.n_layers && !rc; ++l) rc = enqueue_layer(c, (int)l);
+        if (!rc) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
+    }
+    hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+    if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// host->device copy of one tensor payload, optionally row-interleaved (dst row = 2*r + phase)
+int upload(lmrs_ctx* c, void* dst, const uint8_t* src, size_t bytes) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int upload_interleaved(lmrs_ctx* c, void* dst, const uint8_t* src, size_t row_bytes, size_t rows, int phase) {
+    HIP_OK(hipMemcpy2DAsync(static_cast<char*>(dst) + phase * row_bytes, 2 * row_bytes, src, row_bytes, row_bytes, rows,
+                            hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end) {
+    c->h_st->pos = (int)pos; c->h_st->prompt_end = (int)prompt_end; c->h_st->step_count = 0; c->h_st->_pad = 0;
+    HIP_OK(hipMemcpyAsync(c->st, c->h_st, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int lmrs_comm_unique_id(void* out128) { (void)out128; return fail("row-sharded multi-GPU path is not built in this round"); }
+
+extern "C" int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid,
+                                   lmrs_ctx** out, size_t* bytes_consumed) {
+    (void)uid;
+    if (world != 1 || rank != 0) return fail("row-sharded multi-GPU path is not built in this round (world must be 1)");
+    return lmrs_create(file, len, device, out, bytes_consumed);
+}
+
+extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx** out, size_t* bytes_consumed) {
+    if (!out) return fail("out is NULL");
+    *out = nullptr;
+    Layout lay; std::string perr;
+    if (!parse_layout(file, len, &lay, &perr)) return fail(perr);
+    const lmrs_args& a = lay.args;
+    if (a.q_type == LMRS_Q_NONE) return fail("q_type None (f32 weights) is not on the HIP hot path; quantised LMRS files only");
+    if (a.group_size != 128) return fail("group_size != 128 is not supported by the HIP kernels (the reference exporter always quantises with 128)");
+    if (a.model_type == LMRS_GEMMA) return fail("GEMMA glue (post-norms) not built yet in the HIP path");
+    const size_t dim = a.dim, att = (size_t)a.n_heads * a.head_size, kv = (size_t)a.n_kv_heads * a.head_size, hid = a.hidden_dim, V = a.vocab_size;
+    if (dim % 128 || att % 128 || hid % 128) return fail("dim, n_heads*head_size and hidden_dim must be multiples of 128");
+    if (dim > 10240 || att > 10240 || hid > 10240) return fail("vector length above 10240 not supported");
+    if (a.head_size % 4 || (a.head_size & 1)) return fail("head_size must be a multiple of 4");
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail("no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("bad device index");
+    HIP_OK(hipSetDevice(device));
+
+    lmrs_ctx* c = new lmrs_ctx();
+    c->args = a; c->lay = lay; c->device = device; c->att_dim = (int)att; c->kv_dim = (int)kv; c->q4 = a.q_type == LMRS_Q4_0;
+    auto cleanup = [&]() { lmrs_destroy(c); return -1; };
+#define CK(call) do { if ((call)) return cleanup(); } while (0)
+#define HCK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return cleanup(); } } while (0)
+    HCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HCK(hipEventCreate(&c->ev0)); HCK(hipEventCreate(&c->ev1));
+
+    const size_t G = 128, bpe_num = c->q4 ? 1 : 2;   // bytes per element = bpe_num / 2
+    auto qbytes = [&](size_t rows, size_t cols) { return rows * cols * bpe_num / 2; };
+    auto sbytes = [&](size_t rows, size_t cols) { return rows * cols / G * 4; };
+    const size_t nl = a.n_layers;
+    size_t total = 0;
+    auto need = [&](size_t b) { total += pad256(b); };
+    for (size_t l = 0; l < nl; ++l) {
+        need(qbytes(att + 2 * kv, dim)); need(sbytes(att + 2 * kv, dim));
+        need(qbytes(dim, att)); need(sbytes(dim, att));
+        need(qbytes(2 * hid, dim)); need(sbytes(2 * hid, dim));
+        need(qbytes(dim, hid)); need(sbytes(dim, hid));
+        for (int i = 0; i < 4; ++i) need(dim * 4);
+    }
+    need(qbytes(V, dim)); need(sbytes(V, dim));
+    if (a.model_type == LMRS_PHI) { need(qbytes(V, dim)); need(sbytes(V, dim)); }
+    need(dim * 4);
+    const size_t kvn = nl * a.seq_len * kv;
+    need(kvn * 4); need(kvn * 4);
+    need((size_t)a.seq_len * a.head_size * 4);                               // rope table
+    need(dim * 4); need(att * 4); need(kv * 4); need(att * 4); need(hid * 4); need(V * 4);
+    need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4);
+    need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
+    c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4);
+    total += 4096;
+    HCK(hipMalloc(reinterpret_cast<void**>(&c->arena), total));
+    c->arena_bytes = total;
+
+    // ---- weights
+    c->layers.resize(nl);
+    for (size_t l = 0; l < nl; ++l) {
+        DevLayer& D = c->layers[l];
+        char* wqkv = c->alloc<char>(qbytes(att + 2 * kv, dim)); float* sqkv = c->alloc<float>(sbytes(att + 2 * kv, dim) / 4);
+        char* wo = c->alloc<char>(qbytes(dim, att)); float* so = c->alloc<float>(sbytes(dim, att) / 4);
+        char* w13 = c->alloc<char>(qbytes(2 * hid, dim)); float* s13 = c->alloc<float>(sbytes(2 * hid, dim) / 4);
+        char* w2 = c->alloc<char>(qbytes(dim, hid)); float* s2 = c->alloc<float>(sbytes(dim, hid) / 4);
+        float* r0 = c->alloc<float>(dim); float* r1 = c->alloc<float>(dim); float* r2 = c->alloc<float>(dim); float* r3 = c->alloc<float>(dim);
+        if (!wqkv || !sqkv || !wo || !so || !w13 || !s13 || !w2 || !s2 || !r3) { fail("arena overflow"); return cleanup(); }
+        const TensorView &tq = lay.wq[l], &tk = lay.wk[l], &tv = lay.wv[l];
+        CK(upload(c, wqkv, file + tq.q_off, tq.q_bytes));
+        CK(upload(c, wqkv + tq.q_bytes, file + tk.q_off, tk.q_bytes));
+        CK(upload(c, wqkv + tq.q_bytes + tk.q_bytes, file + tv.q_off, tv.q_bytes));
+        CK(upload(c, sqkv, file + tq.s_off, tq.s_bytes));
+        CK(upload(c, reinterpret_cast<char*>(sqkv) + tq.s_bytes, file + tk.s_off, tk.s_bytes));
+        CK(upload(c, reinterpret_cast<char*>(sqkv) + tq.s_bytes + tk.s_bytes, file + tv.s_off, tv.s_bytes));
+        CK(upload(c, wo, file + lay.wo[l].q_off, lay.wo[l].q_bytes));
+        CK(upload(c, so, file + lay.wo[l].s_off, lay.wo[l].s_bytes));
+        const size_t rb = qbytes(1, dim), srb = dim / G * 4;
+        CK(upload_interleaved(c, w13, file + lay.w1[l].q_off, rb, hid, 0));
+        CK(upload_interleaved(c, w13, file + lay.w3[l].q_off, rb, hid, 1));
+        CK(upload_interleaved(c, s13, file + lay.w1[l].s_off, srb, hid, 0));
+        CK(upload_interleaved(c, s13, file + lay.w3[l].s_off, srb, hid, 1));
+        CK(upload(c, w2, file + lay.w2[l].q_off, lay.w2[l].q_bytes));
+        CK(upload(c, s2, file + lay.w2[l].s_off, lay.w2[l].s_bytes));
+        CK(upload(c, r0, file + lay.rms_att[l].q_off, dim * 4));
+        CK(upload(c, r1, file + lay.rms_post_att[l].q_off, dim * 4));
+        if (a.model_type == LMRS_GEMMA) {
+            CK(upload(c, r2, file + lay.rms_pre_ffn[l].q_off, dim * 4));
+            CK(upload(c, r3, file + lay.rms_post_ffn[l].q_off, dim * 4));
+        }
+        D.wqkv = wqkv; D.sqkv = sqkv; D.wo = wo; D.so = so; D.w13 = w13; D.s13 = s13; D.w2 = w2; D.s2 = s2;
+        D.rms_att = r0; D.rms_post_att = r1; D.rms_pre_ffn = r2; D.rms_post_ffn = r3;
+    }
+    {
+        char* eq = c->alloc<char>(lay.emb.q_bytes); float* es = c->alloc<float>(lay.emb.s_bytes / 4);
+        if (!eq || !es) { fail("arena overflow"); return cleanup(); }
+        CK(upload(c, eq, file + lay.emb.q_off, lay.emb.q_bytes)); CK(upload(c, es, file + lay.emb.s_off, lay.emb.s_bytes));
+        c->emb_q = eq; c->emb_s = es; c->cls_q = eq; c->cls_s = es;        // tied classifier = the QUANTISED table
+        if (a.model_type == LMRS_PHI) {
+            char* hq = c->alloc<char>(lay.lm_head.q_bytes); float* hs = c->alloc<float>(lay.lm_head.s_bytes / 4);
+            if (!hq || !hs) { fail("arena overflow"); return cleanup(); }
+            CK(upload(c, hq, file + lay.lm_head.q_off, lay.lm_head.q_bytes)); CK(upload(c, hs, file + lay.lm_head.s_off, lay.lm_head.s_bytes));
+            c->cls_q = hq; c->cls_s = hs;
+        }
+        float* rf = c->alloc<float>(dim);
+        CK(upload(c, rf, file + lay.rms_final.q_off, dim * 4));
+        c->rms_final = rf;
+    }
+    // ---- state
+    c->k_cache = c->alloc<float>(kvn); c->v_cache = c->alloc<float>(kvn);
+    c->rope = c->alloc<float>((size_t)a.seq_len * a.head_size);
+    c->x = c->alloc<float>(dim); c->q = c->alloc<float>(att); c->k_raw = c->alloc<float>(kv); c->att_out = c->alloc<float>(att);
+    c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V);
+    c->part_val = c->alloc<float>(kMaxArgmaxParts); c->part_idx = c->alloc<int>(kMaxArgmaxParts);
+    c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
+    c->stage = c->alloc<float>(c->stage_floats);
+    if (!c->stage) { fail("arena overflow"); return cleanup(); }
+    HCK(hipMemsetAsync(c->k_cache, 0, kvn * 4, c->stream)); HCK(hipMemsetAsync(c->v_cache, 0, kvn * 4, c->stream));   // :302-303
+    HCK(hipMemsetAsync(c->tokens, 0, ((size_t)a.seq_len + 8) * 4, c->stream));
+    HCK(hipMemsetAsync(c->logits, 0, V * 4, c->stream));
+    {
+        const uint32_t half = a.head_size / 2;
+        std::vector<float> tab((size_t)a.seq_len * a.head_size);
+        for (uint32_t p = 0; p < a.seq_len; ++p)
+            for (uint32_t j = 0; j < half; ++j) rope_terms(a, p, j, &tab[((size_t)p * half + j) * 2], &tab[((size_t)p * half + j) * 2 + 1]);
+        HCK(hipMemcpyAsync(c->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HCK(hipStreamSynchronize(c->stream));       // tab goes out of scope
+    }
+    HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_logits), V * 4, hipHostMallocDefault));
+    HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_tok), ((size_t)a.seq_len + 8) * 4, hipHostMallocDefault));
+    HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_st), sizeof(DevState), hipHostMallocDefault));
+    CK(set_state(c, 0, 0));
+    HCK(hipStreamSynchronize(c->stream));
+    {
+        GemvArgs g = cls_args(c);
+        c->cls_grid = gemv_grid(g, EPI_CLS);
+    }
+    CK(capture(c, true, &c->g_step));
+    CK(capture(c, false, &c->g_layers));
+#undef CK
+#undef HCK
+    *out = c;
+    if (bytes_consumed) *bytes_consumed = lay.end;
+    return 0;
+}
+
+extern "C" void lmrs_destroy(lmrs_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->g_step) hipGraphExecDestroy(c->g_step);
+    if (c->g_layers) hipGraphExecDestroy(c->g_layers);
+    if (c->h_logits) hipHostFree(c->h_logits);
+    if (c->h_tok) hipHostFree(c->h_tok);
+    if (c->h_st) hipHostFree(c->h_st);
+    if (c->arena) hipFree(c->arena);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const lmrs_args* lmrs_get_args(const lmrs_ctx* c) { return c ? &c->args : nullptr; }
+
+static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
+    if (!c) return fail("ctx is NULL");
+    if (token >= c->args.vocab_size) return fail("token out of range");
+    if (pos >= c->args.seq_len) return fail("pos out of range (seq_len is clamped to 8192)");
+    HIP_OK(hipSetDevice(c->device));
+    c->h_tok[0] = token;
+    HIP_OK(hipMemcpyAsync(c->tokens + pos, c->h_tok, 4, hipMemcpyHostToDevice, c->stream));
+    if (set_state(c, pos, 0)) return -1;
+    HIP_OK(hipGraphLaunch(c->g_step, c->stream));
+    return 0;
+}
+
+extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** logits) {
+    if (step_once(c, token, pos)) return -1;
+    HIP_OK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->args.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (logits) *logits = c->h_logits;
+    return 0;
+}
+
+extern "C" int lmrs_forward_argmax(lmrs_ctx* c, uint32_t token, uint32_t pos, uint32_t* next) {
+    if (step_once(c, token, pos)) return -1;
+    HIP_OK(hipMemcpyAsync(c->h_tok + 1, c->tokens + pos + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (next) *next = c->h_tok[1];
+    return 0;
+}
+
+extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, size_t n, float* out) {
+    lmrs_ctx* c = const_cast<lmrs_ctx*>(cc);
+    if (!c || !tokens || !out) return fail("NULL argument");
+    HIP_OK(hipSetDevice(c->device));
+    const size_t dim = c->args.dim, chunk = c->stage_floats / dim < 64 ? c->stage_floats / dim : 64;
+    uint32_t* dtok = reinterpret_cast<uint32_t*>(c->stage + c->stage_floats);   // 64 ints after the staging floats
+    for (size_t i0 = 0; i0 < n; i0 += chunk) {
+        const size_t m = n - i0 < chunk ? n - i0 : chunk;
+        for (size_t i = 0; i < m; ++i) if (tokens[i0 + i] >= c->args.vocab_size) return fail("token out of range");
+        HIP_OK(hipMemcpyAsync(dtok, tokens + i0, m * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(launch_dequant_rows(c->emb_q, c->emb_s, c->q4, dtok, (int)m, (int)dim, c->stage, c->stream));
+        HIP_OK(hipMemcpyAsync(out + i0 * dim, c->stage, m * dim * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, uint32_t curr_pos, uint32_t* new_pos) {
+    if (!c || !embeddings) return fail("NULL argument");
+    if ((size_t)curr_pos + n > c->args.seq_len) return fail("positions out of range");
+    HIP_OK(hipSetDevice(c->device));
+    // forward_layer(sl = n) for every layer is, value for value, n single-token passes through the
+    // layers (causal; each token's arithmetic only sees tokens <= itself), so the decode graph is reused.
+    const size_t dim = c->args.dim;
+    if (set_state(c, curr_pos, 0)) return -1;
+    for (uint32_t i = 0; i < n; ++i) {
+        HIP_OK(hipMemcpyAsync(c->x, embeddings + (size_t)i * dim, dim * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipGraphLaunch(c->g_layers, c->stream));
+        HIP_OK(hipMemcpyAsync(embeddings + (size_t)i * dim, c->x, dim * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (new_pos) *new_pos = curr_pos + n;
+    return 0;
+}
+
+extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t n_prompt, uint32_t n_new, uint32_t start_pos,
+                                    uint32_t* out_tokens, double* seconds) {
+    if (!c || !prompt || (!out_tokens && n_new)) return fail("NULL argument");
+    if (n_prompt == 0) return fail("empty prompt");
+    const size_t steps = n_prompt + (n_new ? n_new - 1 : 0);
+    if ((size_t)start_pos + steps > c->args.seq_len) return fail("prompt + generation exceeds seq_len");
+    for (size_t i = 0; i < n_prompt; ++i) if (prompt[i] >= c->args.vocab_size) return fail("token out of range");
+    HIP_OK(hipSetDevice(c->device));
+    memcpy(c->h_tok, prompt, n_prompt * 4);
+    HIP_OK(hipMemcpyAsync(c->tokens + start_pos, c->h_tok, n_prompt * 4, hipMemcpyHostToDevice, c->stream));
+    if (set_state(c, start_pos, start_pos + (uint32_t)n_prompt)) return -1;
+    HIP_OK(hipEventRecord(c->ev0, c->stream));
+    for (size_t s = 0; s < steps; ++s) HIP_OK(hipGraphLaunch(c->g_step, c->stream));
+    HIP_OK(hipEventRecord(c->ev1, c->stream));
+    if (n_new) HIP_OK(hipMemcpyAsync(c->h_tok, c->tokens + start_pos + n_prompt, (size_t)n_new * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (n_new) memcpy(out_tokens, c->h_tok, (size_t)n_new * 4);
+    if (seconds) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *seconds = ms * 1e-3; }
+    return 0;
+}
+
+// ------------------------------------------------------------------ measurement hooks
+// The GEMV launches of one decode step, in step order (per layer qkv, wo, w1w3, w2; then the classifier),
+// so that the weight stream is the real one (1.27 GB for Llama-3.2-1B: nothing is re-served by the 256 MiB
+// Infinity Cache), each launch bracketed by HIP events on the context's stream.
+extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* bytes5, int* count5) {
+    if (!c || iters <= 0 || !us5 || !bytes5 || !count5) return fail("bad argument");
+    HIP_OK(hipSetDevice(c->device));
+    const lmrs_args& a = c->args;
+    const int nl = (int)a.n_layers, n_launch = 4 * nl + 1;
+    std::vector<hipEvent_t> ev(2 * (size_t)n_launch);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    const double bpe = c->q4 ? 0.5 : 1.0;
+    for (int k = 0; k < 5; ++k) { us5[k] = 0; bytes5[k] = 0; count5[k] = 0; }
+    auto mk = [&](int which, int layer, GemvArgs& g, int& pro, int& epi) {
+        const DevLayer& L = c->layers[layer];
+        g = GemvArgs{}; pro = PRO_QUANT; epi = EPI_STORE;
+        g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = a.model_type == LMRS_GEMMA; g.st = c->st;
+        g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = layer;
+        switch (which) {
+            case 0: g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim; g.xin = c->x; g.rms_w = L.rms_att;
+                    g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache; pro = PRO_RMS_QUANT; epi = EPI_QKV; break;
+            case 1: g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = c->x; epi = EPI_RESID; break;
+            case 2: g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h;
+                    pro = PRO_RMS_QUANT; epi = EPI_SWIGLU; break;
+            case 3: g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = c->x; epi = EPI_RESID; break;
+            default: g = cls_args(c); pro = PRO_RMS_QUANT; epi = EPI_CLS; break;
+        }
+    };
+    if (set_state(c, 0, 0)) return -1;
+    for (int it = -1; it < iters; ++it) {              // it == -1: untimed warm-up pass
+        int i = 0;
+        for (int l = 0; l <= nl; ++l)
+            for (int which = (l < nl ? 0 : 4); which < (l < nl ? 4 : 5); ++which) {
+                GemvArgs g; int pro, epi; mk(which, l < nl ? l : 0, g, pro, epi);
+                HIP_OK(hipEventRecord(ev[2 * i], c->stream));
+                HIP_OK(launch_gemv(g, pro, epi, c->stream));
+                HIP_OK(hipEventRecord(ev[2 * i + 1], c->stream));
+                ++i;
+            }
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (it < 0) continue;
+        i = 0;
+        for (int l = 0; l <= nl; ++l)
+            for (int which = (l < nl ? 0 : 4); which < (l < nl ? 4 : 5); ++which) {
+                GemvArgs g; int pro, epi; mk(which, l < nl ? l : 0, g, pro, epi);
+                float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+                us5[which] += (double)ms * 1e3; bytes5[which] += (double)g.o * g.n * (bpe + 4.0 / 128.0); count5[which] += 1;
+                ++i;
+            }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, double* algo_bytes) {
+    if (!c) return fail("ctx is NULL");
+    const lmrs_args& a = c->args;
+    const double bpe = c->q4 ? 0.5 : 1.0, dim = a.dim, att = c->att_dim, kv = c->kv_dim, hid = a.hidden_dim, V = a.vocab_size, L = a.n_layers;
+    const double n_norm = a.model_type == LMRS_GEMMA ? 4 : 2;
+    // weights + scales once, norm weights, KV read/write at this position
+    double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
+               dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
+    if (algo_bytes) *algo_bytes = b;
+    if (n_launches) *n_launches = 1 + 5 * (int)a.n_layers + 2;
+    return 0;
+}
+
+// ------------------------------------------------------------------ L2 free functions (unit parity)
+namespace {
+struct Scratch {          // RAII device buffers for the op entry points
+    std::vector<void*> p;
+    ~Scratch() { for (void* q : p) hipFree(q); }
+    void* get(size_t bytes) { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 4) != hipSuccess) return nullptr; p.push_back(q); return q; }
+};
+int op_begin(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail("bad device index");
+    HIP_OK(hipSetDevice(device));
+    return 0;
+}
+}  // namespace
+
+extern "C" int lmrs_op_matmul_q8(int device, float* xout, const int8_t* xq, const float* xs, const int8_t* wq, const float* ws,
+                                 size_t n, size_t o, size_t gs, size_t sl) {
+    if (op_begin(device)) return -1;
+    if (gs != 128 || n % 128) return fail("group size must be 128 and n a multiple of it");
+    Scratch S; const size_t G = n / 128;
+    void *dx = S.get(sl * n), *dxs = S.get(sl * G * 4), *dw = S.get(o * n), *dws = S.get(o * G * 4), *dout = S.get(sl * o * 4);
+    if (!dout) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, xq, sl * n, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dxs, xs, sl * G * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dw, wq, o * n, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dws, ws, o * G * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(dout, 0, sl * o * 4));
+    const size_t o4 = o / 4 * 4;                       // par_chunks_exact_mut(4): tail rows are never written
+    for (size_t t = 0; t < sl && o4; ++t) {
+        GemvArgs g{}; g.wq = dw; g.ws = static_cast<float*>(dws); g.n = (int)n; g.o = (int)o4;
+        g.xq_in = static_cast<char*>(dx) + t * n; g.xs_in = static_cast<float*>(dxs) + t * G; g.out = static_cast<float*>(dout) + t * o;
+        HIP_OK(launch_gemv(g, PRO_PREQ, EPI_STORE, nullptr));
+    }
+    HIP_OK(hipMemcpy(xout, dout, sl * o * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lmrs_op_matmul_q4(int device, float* xout, const uint8_t* xq, const float* xs, const uint8_t* wq, const float* ws,
+                                 size_t n, size_t o, size_t gs) {
+    if (op_begin(device)) return -1;
+    if (gs != 128 || n % 128) return fail("group size must be 128 and n a multiple of it");
+    Scratch S; const size_t G = n / 128;
+    void *dx = S.get(n / 2), *dxs = S.get(G * 4), *dw = S.get(o * n / 2), *dws = S.get(o * G * 4), *dout = S.get(o * 4);
+    if (!dout) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, xq, n / 2, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dxs, xs, G * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dw, wq, o * n / 2, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dws, ws, o * G * 4, hipMemcpyHostToDevice));
+    GemvArgs g{}; g.q4 = 1; g.wq = dw; g.ws = static_cast<float*>(dws); g.n = (int)n; g.o = (int)o;
+    g.xq_in = dx; g.xs_in = static_cast<float*>(dxs); g.out = static_cast<float*>(dout);
+    HIP_OK(launch_gemv(g, PRO_PREQ, EPI_STORE, nullptr));
+    HIP_OK(hipMemcpy(xout, dout, o * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static int op_quant(int device, void* q, float* s, const float* x, size_t n, size_t gs, int q4) {
+    if (op_begin(device)) return -1;
+    if (gs != 128 || n % 128) return fail("group size must be 128 and n a multiple of it");
+    Scratch S; const size_t qb = q4 ? n / 2 : n;
+    const size_t chunk = 8192;                         // one workgroup quantises up to 10240 elements; groups are independent
+    void *dx = S.get(n * 4), *dq = S.get(qb), *ds = S.get(n / 128 * 4);
+    if (!ds) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    for (size_t e0 = 0; e0 < n; e0 += chunk) {
+        const size_t m = n - e0 < chunk ? n - e0 : chunk;
+        HIP_OK(launch_quantize(static_cast<float*>(dx) + e0, static_cast<char*>(dq) + (q4 ? e0 / 2 : e0), static_cast<float*>(ds) + e0 / 128, (int)m, q4, nullptr));
+    }
+    HIP_OK(hipMemcpy(q, dq, qb, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(s, ds, n / 128 * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int lmrs_op_quantize(int device, int8_t* q, float* s, const float* x, size_t n, size_t gs) { return op_quant(device, q, s, x, n, gs, 0); }
+extern "C" int lmrs_op_quantize_q4(int device, uint8_t* q, float* s, const float* x, size_t n, size_t gs) { return op_quant(device, q, s, x, n, gs, 1); }
+
+extern "C" int lmrs_op_rmsnorm(int device, float* o, const float* x, const float* weight, size_t size, float eps, int add_unit_offset) {
+    if (op_begin(device)) return -1;
+    Scratch S; void *dx = S.get(size * 4), *dw = S.get(size * 4), *dout = S.get(size * 4);
+    if (!dout) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, x, size * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dw, weight, size * 4, hipMemcpyHostToDevice));
+    HIP_OK(launch_rmsnorm(static_cast<float*>(dx), static_cast<float*>(dw), static_cast<float*>(dout), (int)size, eps, add_unit_offset, nullptr));
+    HIP_OK(hipMemcpy(o, dout, size * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lmrs_op_softmax(int device, float* x, size_t n) {
+    if (op_begin(device)) return -1;
+    if (n == 0) return fail("empty input (the reference indexes x[0])");
+    Scratch S; void* dx = S.get(n * 4);
+    if (!dx) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    HIP_OK(launch_softmax(static_cast<float*>(dx), (int)n, nullptr));
+    HIP_OK(hipMemcpy(x, dx, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lmrs_op_expf(int device, float* y, const float* x, size_t n) {
+    if (op_begin(device)) return -1;
+    Scratch S; void *dx = S.get(n * 4), *dy = S.get(n * 4);
+    if (!dy) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    HIP_OK(launch_expf(static_cast<float*>(dx), static_cast<float*>(dy), n, nullptr));
+    HIP_OK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,99 @@
+// lmrs_device_math.h — bit-exact device arithmetic shared by every kernel of the decode path.
+//
+// Everything here is written so that the GPU reproduces, bit for bit, what the reference's CPU
+// code computes (reference src/functional.rs, src/quantization.rs); the file is compiled with
+// -ffp-contract=off, so a*b+c below is two rounded operations unless __builtin_fma is spelled out.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lmrs {
+
+// ---------------------------------------------------------------- cross-lane (wave64, DPP)
+// quad_perm[1,0,3,2] / quad_perm[2,3,0,1] / row_half_mirror / row_mirror: no LDS traffic.
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+
+// Sum over each aligned cluster of 8 lanes; exact (integers); every lane of the cluster gets the total.
+__device__ __forceinline__ int cluster8_sum(int v) {
+    v += dpp_i<0xB1>(v);
+    v += dpp_i<0x4E>(v);
+    v += dpp_i<0x141>(v);
+    return v;
+}
+// Max over each aligned group of 32 lanes (one 128-element quantisation group at 4 elements per lane).
+__device__ __forceinline__ float group32_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return v;
+}
+
+// ---------------------------------------------------------------- f32::exp == glibc expf
+// Restatement of glibc >= 2.27 expf (sysdeps/ieee754/flt-32/e_expf.c; N = 32 table + cubic in double)
+// as compiled for x86-64 CPUs with FMA (the ifunc'd __expf_fma build, where GCC fuses every a*b+c).
+// oracle/expf_check.c compares exactly this operation sequence with the host libm over all 2^32
+// inputs (0 mismatches in the build container); tests/test_gpu_ops.py repeats the comparison
+// device-vs-host on the GPU box.  Used by softmax (functional.rs:133) and SiLU (transformer.rs:617).
+__device__ const uint64_t EXP2F_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float expf_glibc(float x) {
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const uint32_t ux = __float_as_uint(x);
+    const uint32_t abstop = (ux >> 20) & 0x7ff;
+    if (abstop >= 0x42b) {                                   // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8) return x + x;
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    const double xd = (double)x;
+    double kd = __builtin_fma(InvLn2N, xd, SHIFT);
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd = kd - SHIFT;
+    const double r = __builtin_fma(InvLn2N, xd, -kd);
+    uint64_t t = EXP2F_TAB[ki % 32];
+    t += ki << (52 - 5);
+    const double s = __longlong_as_double((long long)t);
+    const double z = __builtin_fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+// ---------------------------------------------------------------- quantize primitives (quantization.rs:44-95)
+// Rust `f32 as i8` after f32::round: saturating, NaN -> 0.
+__device__ __forceinline__ int quant_q8(float x, float scale) {
+    float q = roundf(x / scale);                              // IEEE divide; round half away from zero
+    if (!(q == q)) return 0;
+    q = fminf(fmaxf(q, -128.0f), 127.0f);
+    return (int)q;
+}
+// ((x/scale + 8.0).round() as u8).clamp(0, 15)
+__device__ __forceinline__ unsigned quant_q4(float x, float scale) {
+    float q = roundf(x / scale + 8.0f);
+    if (!(q == q)) return 0u;
+    q = fminf(fmaxf(q, 0.0f), 15.0f);
+    return (unsigned)q;
+}
+
+// wide 0.7.x f32x8::reduce_add (AVX path): ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)).
+__device__ __forceinline__ float reduce_add8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    const float q0 = v0 + v4, q1 = v1 + v5, q2 = v2 + v6, q3 = v3 + v7;
+    const float d0 = q0 + q2, d1 = q1 + q3;
+    return d0 + d1;
+}
+
+}  // namespace lmrs

@@ -1,0 +1,77 @@
+// lmrs_kernels.h — launch interface of the HIP kernels of the lm.rs decode hot path (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lmrs {
+
+// Device-resident step state: lets one captured hipGraph be replayed for every token (no
+// per-step parameter updates, no host round trip between tokens).
+struct DevState {
+    int pos;          // position of the token being processed
+    int prompt_end;   // absolute position from which the argmax is written back as the next input
+    int step_count;   // statistics
+    int _pad;
+};
+
+enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2 };
+enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5 };
+
+struct GemvArgs {
+    // weights: o rows of n int8 (Q8_0) / n/2 bytes (Q4_0), row-major; scales o * (n/128) f32
+    const void* wq; const float* ws;
+    int n, o;
+    int q4;                  // 0: Q8_0, 1: Q4_0
+    // activation input
+    const float* xin;        // PRO_QUANT / PRO_RMS_QUANT: n f32
+    const void* xq_in; const float* xs_in;   // PRO_PREQ: already quantised activation
+    const float* rms_w; float eps; int add_unit;   // PRO_RMS_QUANT
+    // outputs
+    float* out;              // STORE: out[o]; RESID: out[i] += ; SWIGLU/GELU: out[o/2]; CLS: logits
+    // EPI_QKV
+    float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer;
+    const DevState* st;
+    // EPI_CLS
+    float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on rows < softcap_rows
+};
+
+struct AttnArgs {
+    const float* q;          // att_dim raw (un-rotated) query
+    const float* k_raw;      // kv_dim raw key of this position
+    float* k_cache; const float* v_cache;     // [layer][seq_len][kv_dim]
+    const float* rope;       // [seq_len][head_size/2][2] = (fcr, fci)
+    float* out;              // att_dim
+    int n_heads, n_kv_heads, head_size, seq_len, layer, gemma;
+    const DevState* st;
+};
+
+struct EmbedArgs {
+    const void* emb_q; const float* emb_s; int q4;
+    const uint32_t* tokens;  // tokens[pos] is the input token
+    float* x; int dim; float scale; int do_scale;   // Gemma: x *= sqrt(dim)
+    const DevState* st;
+};
+
+struct ArgmaxArgs {
+    const float* part_val; const int* part_idx; int n_part;
+    const float* logits;
+    uint32_t* tokens; DevState* st;
+};
+
+// launches (all asynchronous on `s`)
+hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint = 0);
+int gemv_grid(const GemvArgs& a, int epi);               // number of workgroups launch_gemv uses
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
+hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s);
+hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint32_t* tokens, int n_tok, int dim, float* out, hipStream_t st);
+
+// thin kernels over the same device functions, for the lmrs_op_* unit-parity entry points
+hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st);
+hipError_t launch_rmsnorm(const float* x, const float* w, float* o, int n, float eps, int add_unit, hipStream_t st);
+hipError_t launch_softmax(float* x, int n, hipStream_t st);
+hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st);
+
+constexpr int kMaxArgmaxParts = 4096;
+
+}  // namespace lmrs

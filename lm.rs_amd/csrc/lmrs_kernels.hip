@@ -1,0 +1,669 @@
+// lmrs_kernels.hip — hand-written HIP kernels (CDNA4 / gfx950, wave64) for the lm.rs decode hot path.
+//
+// What each kernel replaces in the reference (samuel-vitorino/lm.rs):
+//   gemv_kernel      src/functional.rs:173-214 matmul_q8 / :216-250 matmul_q4, with the producers and
+//                    consumers that surround every call fused in:
+//                      prologue  rmsnorm (functional.rs:48-78) + quantize (quantization.rs:44-95)
+//                      epilogue  residual add (transformer.rs:574-576, 652-654), K/V-cache store
+//                                (:413-416), SiLU*up / GELU*up (:607-624), logits + argmax partials
+//                                (:355-381, sampler.rs:29-41)
+//   attention_kernel src/transformer.rs:443-544 (RoPE, scores, softmax, weighted V sum)
+//   embed_kernel     src/transformer.rs:324-332 (+ quantization.rs:25-42 dequantize of one row)
+//   argmax_final     src/sampler.rs:29-41
+//
+// Arithmetic contract: every float result is bit-identical to the CPU path:
+//   integer group sums are exact in any order; float accumulation follows the reference's order
+//   (groups ascending per row; 8 strided partials + wide's reduce tree for RMSNorm; sequential over
+//   t for softmax sum and the V accumulation); no FMA contraction (-ffp-contract=off); IEEE div/sqrt.
+//
+// Mapping for MI355X: decode GEMV is HBM-bound (1 int8 MAC per weight byte), so the design goal is
+// "every weight byte crosses HBM once, 16 B per lane, as many bytes in flight as the chip accepts":
+//   - a row is read by L lanes (L = 8..64) x 16 B per step; an aligned cluster of 8 lanes (Q8_0) or
+//     4 lanes (Q4_0) covers exactly one 128-element quantisation group, so the group's int32 sum is
+//     a 3-step (2-step) DPP butterfly and the per-group float combine needs no cross-lane traffic
+//     when L == cluster size; U steps (<= 16 KiB per wave) are issued back to back before first use;
+//   - weights are loaded non-temporally (read once); the quantised activation vector lives in LDS
+//     (n bytes + n/128 scales), read with conflict-free ds_read_b128 broadcasts;
+//   - the activation prologue (RMSNorm / quantise) is recomputed by every workgroup from the
+//     L2-resident f32 vector: it runs while the workgroup's first weight loads are in flight and
+//     saves a dependent kernel boundary (~1.2-1.9 us on this chip) per use.
+#include "lmrs_device_math.h"
+#include "lmrs_kernels.h"
+
+namespace lmrs {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr int kGS = 128;             // quantisation group size (the reference exporter always uses 128)
+
+// ------------------------------------------------------------------------------------------------
+// Activation prologue device functions (shared by the fused GEMV and the lmrs_op_* kernels)
+// ------------------------------------------------------------------------------------------------
+
+// Thread t owns elements e = i*1024 + 4t .. +3 for i = 0..P-1  (P = ceil(n / 1024)), so that 32
+// consecutive lanes own one 128-element quantisation group.
+constexpr int kMaxP = 10;            // n <= 10240
+
+// RMSNorm (functional.rs:48-78) of x[n] (held in v[]), result written back into v[].
+// scratch: (8 * (n/8 + 4) + 1) floats of LDS.
+__device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[kMaxP], int n, const float* __restrict__ w, float eps,
+                                                int add_unit, float* scratch) {
+    const int t = threadIdx.x;
+    const int P = (n + 1023) >> 10;
+    const int JP = (n >> 3) + 4;                 // padded row length of the transposed square table
+    // squares, transposed: T[k][j] = x[8j+k]^2 so that lane k walks j contiguously
+#pragma unroll
+    for (int i = 0; i < kMaxP; ++i) {
+        if (i < P) {
+            const int e = i * 1024 + t * 4;
+            if (e < n) {
+                const int j = e >> 3, k0 = e & 7;          // k0 in {0, 4}
+                scratch[(k0 + 0) * JP + j] = v[i].x * v[i].x;
+                scratch[(k0 + 1) * JP + j] = v[i].y * v[i].y;
+                scratch[(k0 + 2) * JP + j] = v[i].z * v[i].z;
+                scratch[(k0 + 3) * JP + j] = v[i].w * v[i].w;
+            }
+        }
+    }
+    __syncthreads();
+    if (t < 64) {
+        // lanes 0..7: the 8 strided partial sums, each a sequential chain over j (ss_sim += x*x)
+        float p = 0.0f;
+        if (t < 8) {
+            const float4* row = reinterpret_cast<const float4*>(scratch + t * JP);
+            const int nj4 = n >> 5;                          // (n/8)/4
+            for (int j = 0; j < nj4; ++j) {
+                const float4 s4 = row[j];
+                p = p + s4.x; p = p + s4.y; p = p + s4.z; p = p + s4.w;
+            }
+            for (int j = nj4 * 4; j < (n >> 3); ++j) p = p + scratch[t * JP + j];
+        }
+        const float p0 = __shfl(p, 0), p1 = __shfl(p, 1), p2 = __shfl(p, 2), p3 = __shfl(p, 3);
+        const float p4 = __shfl(p, 4), p5 = __shfl(p, 5), p6 = __shfl(p, 6), p7 = __shfl(p, 7);
+        if (t == 0) {
+            float ss = reduce_add8(p0, p1, p2, p3, p4, p5, p6, p7);
+            ss = ss / (float)n;
+            ss = ss + eps;
+            ss = 1.0f / sqrtf(ss);
+            scratch[8 * JP] = ss;
+        }
+    }
+    __syncthreads();
+    const float ss = scratch[8 * JP];
+#pragma unroll
+    for (int i = 0; i < kMaxP; ++i) {
+        if (i < P) {
+            const int e = i * 1024 + t * 4;
+            if (e < n) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + e);
+                float4 o;
+                if (add_unit) {
+                    o.x = (1.0f + wv.x) * (ss * v[i].x); o.y = (1.0f + wv.y) * (ss * v[i].y);
+                    o.z = (1.0f + wv.z) * (ss * v[i].z); o.w = (1.0f + wv.w) * (ss * v[i].w);
+                } else {
+                    o.x = wv.x * (ss * v[i].x); o.y = wv.y * (ss * v[i].y);
+                    o.z = wv.z * (ss * v[i].z); o.w = wv.w * (ss * v[i].w);
+                }
+                v[i] = o;
+            }
+        }
+    }
+}
+
+// quantize (quantization.rs:44-67) / quantize_q4 (:69-95) of the vector held in v[] into LDS.
+//   Q8_0: xq[e] = int8                                     (n bytes)
+//   Q4_0: xq holds the UNPACKED signed nibble values (q-8), de-interleaved per 8 elements as
+//         [e0 e2 e4 e6 | e1 e3 e5 e7] so that they line up with (w & 0x0F0F0F0F) / (w >> 4 & ...).
+// If gq/gs_out are non-null (lmrs_op_quantize), block 0 also writes the reference's packed form.
+template <bool Q4>
+__device__ __forceinline__ void quantize_to_lds(const float4 (&v)[kMaxP], int n, int8_t* xq, float* xs, void* gq, float* gs_out) {
+    const int t = threadIdx.x;
+    const int P = (n + 1023) >> 10;
+#pragma unroll
+    for (int i = 0; i < kMaxP; ++i) {
+        if (i < P) {
+            const int e = i * 1024 + t * 4;
+            const bool live = e < n;
+            float m = 0.0f;
+            if (live) m = fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+            m = group32_max(m);                       // wmax of the 128-group (max is order-free)
+            if (live) {
+                if constexpr (!Q4) {
+                    const float scale = m / 127.0f;
+                    const int q0 = quant_q8(v[i].x, scale), q1 = quant_q8(v[i].y, scale);
+                    const int q2 = quant_q8(v[i].z, scale), q3 = quant_q8(v[i].w, scale);
+                    const unsigned packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
+                    *reinterpret_cast<unsigned*>(xq + e) = packed;
+                    if ((t & 31) == 0) xs[e >> 7] = scale;
+                    if (gq) {
+                        *reinterpret_cast<unsigned*>(reinterpret_cast<int8_t*>(gq) + e) = packed;
+                        if ((t & 31) == 0) gs_out[e >> 7] = scale;
+                    }
+                } else {
+                    const float scale = m / -8.0f;
+                    const unsigned a = quant_q4(v[i].x, scale), b = quant_q4(v[i].y, scale);
+                    const unsigned c = quant_q4(v[i].z, scale), d = quant_q4(v[i].w, scale);
+                    // elements e..e+3 sit at in-octet positions k0..k0+3 (k0 = e & 7 in {0,4})
+                    const int base = e & ~7, k0 = e & 7;
+                    xq[base + (k0 >> 1) + 0] = (int8_t)((int)a - 8);        // even element -> low-nibble lane
+                    xq[base + 4 + (k0 >> 1) + 0] = (int8_t)((int)b - 8);    // odd element  -> high-nibble lane
+                    xq[base + (k0 >> 1) + 1] = (int8_t)((int)c - 8);
+                    xq[base + 4 + (k0 >> 1) + 1] = (int8_t)((int)d - 8);
+                    if ((t & 31) == 0) xs[e >> 7] = scale;
+                    if (gq) {
+                        uint8_t* g8 = reinterpret_cast<uint8_t*>(gq);
+                        g8[(e >> 1) + 0] = (uint8_t)(a | (b << 4));
+                        g8[(e >> 1) + 1] = (uint8_t)(c | (d << 4));
+                        if ((t & 31) == 0) gs_out[e >> 7] = scale;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_vec(float4 (&v)[kMaxP], const float* __restrict__ x, int n) {
+    const int t = threadIdx.x;
+    const int P = (n + 1023) >> 10;
+#pragma unroll
+    for (int i = 0; i < kMaxP; ++i) {
+        if (i < P) {
+            const int e = i * 1024 + t * 4;
+            if (e < n) v[i] = *reinterpret_cast<const float4*>(x + e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused dequant-GEMV
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));     // native vector: what the nontemporal builtin accepts
+__device__ __forceinline__ i32x4 ld_nt(const i32x4* p) { return __builtin_nontemporal_load(p); }
+
+// signed-nibble unpack of 4 packed bytes: per byte (v & 0xF) - 8 without cross-byte borrows
+__device__ __forceinline__ int nib_signed(unsigned v) { return (int)((((v & 0x0F0F0F0Fu) | 0x80808080u) - 0x08080808u) ^ 0x80808080u); }
+
+template <bool Q4>
+__device__ __forceinline__ int group_partial_dot(const i32x4& w, const int8_t* xq_lds, int chunk) {
+    int d = 0;
+    if constexpr (!Q4) {
+        const int4 x = *reinterpret_cast<const int4*>(xq_lds + chunk * 16);
+        d = __builtin_amdgcn_sdot4(w.x, x.x, d, false);
+        d = __builtin_amdgcn_sdot4(w.y, x.y, d, false);
+        d = __builtin_amdgcn_sdot4(w.z, x.z, d, false);
+        d = __builtin_amdgcn_sdot4(w.w, x.w, d, false);
+    } else {
+        // 16 weight bytes = 32 elements = 32 bytes of unpacked x: per dword [lo lanes | hi lanes]
+        const int4 xa = *reinterpret_cast<const int4*>(xq_lds + chunk * 32);
+        const int4 xb = *reinterpret_cast<const int4*>(xq_lds + chunk * 32 + 16);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.x), xa.x, d, false);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.x >> 4), xa.y, d, false);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.y), xa.z, d, false);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.y >> 4), xa.w, d, false);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.z), xb.x, d, false);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.z >> 4), xb.y, d, false);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.w), xb.z, d, false);
+        d = __builtin_amdgcn_sdot4(nib_signed((unsigned)w.w >> 4), xb.w, d, false);
+    }
+    return d;
+}
+
+// L lanes per row, U steps in flight, PRO/EPI fused stages, Q4 = packed-nibble weights.
+// CL = lanes covering one quantisation group: 8 (Q8_0: 8 x 16 B = 128 B) or 4 (Q4_0: 4 x 16 B = 64 B).
+template <int L, int U, int PRO, int EPI, bool Q4>
+__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CL = Q4 ? 4 : 8;
+    static_assert(L >= CL && (L & (L - 1)) == 0 && L <= 64, "bad L");
+    const int n = a.n, G = n / kGS;
+    int8_t* xq = reinterpret_cast<int8_t*>(smem);                       // n bytes
+    float* xs = reinterpret_cast<float*>(smem + ((n + 15) & ~15));      // G floats
+    float* scratch = xs + ((G + 3) & ~3);
+
+    // ---------------- prologue: build the quantised activation vector in LDS
+    if constexpr (PRO == PRO_PREQ) {
+        if constexpr (!Q4) {
+            for (int e = threadIdx.x * 16; e < n; e += kBlock * 16)
+                *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
+        } else {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(a.xq_in);
+            for (int b = threadIdx.x * 4; b < n / 2; b += kBlock * 4) {   // 4 packed bytes = one octet of elements
+                const unsigned v = *reinterpret_cast<const unsigned*>(src + b);
+                *reinterpret_cast<int*>(xq + 2 * b) = nib_signed(v);
+                *reinterpret_cast<int*>(xq + 2 * b + 4) = nib_signed(v >> 4);
+            }
+        }
+        for (int g = threadIdx.x; g < G; g += kBlock) xs[g] = a.xs_in[g];
+    } else {
+        float4 v[kMaxP];
+        load_vec(v, a.xin, n);
+        if constexpr (PRO == PRO_RMS_QUANT) rmsnorm_inplace(v, n, a.rms_w, a.eps, a.add_unit, scratch);
+        quantize_to_lds<Q4>(v, n, xq, xs, nullptr, nullptr);
+    }
+    __syncthreads();
+
+    // ---------------- main loop
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane % L;                       // lane within the row
+    constexpr int RW = 64 / L;                    // rows per wave
+    constexpr int RB = RW * (kBlock / 64);        // rows per workgroup pass
+    const int row_bytes = Q4 ? n / 2 : n;
+    const int steps = row_bytes / (16 * L);
+    const int o = a.o;
+    const int n_pass = (o + RB - 1) / RB;
+
+    float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;   // EPI_CLS
+
+    for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+        const int row = pass * RB + wave * RW + lane / L;
+        const bool valid = row < o;
+        const int rowc = valid ? row : o - 1;
+        const i32x4* wrow = reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(a.wq) + (size_t)rowc * row_bytes) + r;
+        const float* srow = a.ws + (size_t)rowc * G;
+        float acc = 0.0f;
+        for (int k0 = 0; k0 < steps; k0 += U) {
+            i32x4 w[U]; float sc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u < steps) {
+                    w[u] = ld_nt(wrow + (k0 + u) * L);
+                    sc[u] = srow[((k0 + u) * L + r) / CL];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u < steps) {
+                    const int chunk = (k0 + u) * L + r;              // 16-byte chunk index within the row
+                    int d = group_partial_dot<Q4>(w[u], xq, chunk);
+                    if constexpr (Q4) { d += dpp_i<0xB1>(d); d += dpp_i<0x4E>(d); }
+                    else d = cluster8_sum(d);
+                    float p = (float)d * sc[u];                      // (ival as f32) * w.s[..]
+                    p = p * xs[chunk / CL];                          //   * x.s[..]
+                    if constexpr (L == CL) acc = acc + p;            // xout += ..., groups ascending
+                    else {
+#pragma unroll
+                        for (int j = 0; j < L / CL; ++j) acc = acc + __shfl(p, (lane & ~(L - 1)) + j * CL);
+                    }
+                }
+        }
+        // ---------------- epilogue (acc is replicated over the row's L lanes)
+        if constexpr (EPI == EPI_STORE) {
+            if (valid && r == 0) a.out[row] = acc;
+        } else if constexpr (EPI == EPI_RESID) {
+            if (valid && r == 0) a.out[row] = a.out[row] + acc;
+        } else if constexpr (EPI == EPI_QKV) {
+            if (valid && r == 0) {
+                if (row < a.att_dim) a.out[row] = acc;
+                else if (row < a.att_dim + a.kv_dim) a.k_raw[row - a.att_dim] = acc;
+                else a.v_cache[((size_t)a.layer * a.seq_len + a.st->pos) * a.kv_dim + (row - a.att_dim - a.kv_dim)] = acc;
+            }
+        } else if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GELU) {
+            // rows are interleaved: 2i = gate (w1) row i, 2i+1 = up (w3) row i
+            const float up = __shfl_down(acc, L);
+            if (valid && r == 0 && ((lane / L) & 1) == 0) {
+                float val = acc;
+                if constexpr (EPI == EPI_SWIGLU) {
+                    const float e = expf_glibc(-val);
+                    const float g = 1.0f / (1.0f + e);
+                    val = val * g;
+                } else {
+                    float cube = 0.044715f * val; cube = cube * val; cube = cube * val;
+                    const float inner = val + cube;
+                    const double th = tanh(0.7978845608028654 * (double)inner);
+                    const float g = 0.5f * (1.0f + (float)th);
+                    val = val * g;
+                }
+                val = val * up;
+                a.out[row >> 1] = val;
+            }
+        } else if constexpr (EPI == EPI_CLS) {
+            if (valid && r == 0) {
+                float vv = acc;
+                if (row < a.softcap_rows) {                   // transformer.rs:375-381 (first `dim` logits only)
+                    vv = vv / 30.0f;
+                    vv = (float)tanh((double)vv);
+                    vv = vv * 30.0f;
+                }
+                a.out[row] = vv;
+                if (vv > best) { best = vv; best_i = row; }   // rows ascend per lane: first maximum kept
+            }
+        }
+    }
+
+    if constexpr (EPI == EPI_CLS) {
+        // workgroup argmax partial: larger value wins, ties -> lower index (== first index of the max)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(best_i, off);
+            if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+        }
+        __syncthreads();                                         // LDS reuse
+        float* rv = reinterpret_cast<float*>(smem); int* ri = reinterpret_cast<int*>(smem + 16);
+        if (lane == 0) { rv[wave] = best; ri[wave] = best_i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w2 = 1; w2 < kBlock / 64; ++w2)
+                if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
+            a.part_val[blockIdx.x] = best; a.part_idx[blockIdx.x] = best_i;
+        }
+    }
+}
+
+static size_t gemv_smem(const GemvArgs& a, int pro) {
+    const int n = a.n, G = n / kGS;
+    size_t s = ((n + 15) & ~15) + (size_t)((G + 3) & ~3) * 4;
+    if (pro == PRO_RMS_QUANT) s += (size_t)(8 * (n / 8 + 4) + 4) * 4;
+    return s < 64 ? 64 : s;
+}
+
+// Lanes per row: smallest power of two whose rows are read in <= 16 steps (everything in flight at once).
+static int pick_L(const GemvArgs& a, int epi) {
+    const int row_bytes = a.q4 ? a.n / 2 : a.n;
+    const int cl = a.q4 ? 4 : 8;
+    int L = cl;
+    while (L < 64 && row_bytes / (16 * L) > 16 && row_bytes % (16 * 2 * L) == 0) L *= 2;
+    if ((epi == EPI_SWIGLU || epi == EPI_GELU) && L > 32) L = 32;
+    return L;
+}
+
+int gemv_grid(const GemvArgs& a, int epi) {
+    const int L = pick_L(a, epi);
+    const int RB = (64 / L) * (kBlock / 64);
+    const int n_pass = (a.o + RB - 1) / RB;
+    const int cap = (epi == EPI_CLS) ? 2048 : 4096;        // classifier: persistent-ish grid, prologue paid once per WG
+    return n_pass < cap ? n_pass : cap;
+}
+
+template <int L, int U, bool Q4>
+static hipError_t launch_LU(const GemvArgs& a, int pro, int epi, int grid, size_t smem, hipStream_t s) {
+#define LMRS_CASE(P, E)                                                                       \
+    if (pro == P && epi == E) {                                                               \
+        hipLaunchKernelGGL((gemv_kernel<L, U, P, E, Q4>), dim3(grid), dim3(kBlock), smem, s, a); \
+        return hipGetLastError();                                                             \
+    }
+    LMRS_CASE(PRO_PREQ, EPI_STORE)
+    LMRS_CASE(PRO_QUANT, EPI_STORE)
+    LMRS_CASE(PRO_QUANT, EPI_RESID)
+    LMRS_CASE(PRO_RMS_QUANT, EPI_STORE)
+    LMRS_CASE(PRO_RMS_QUANT, EPI_QKV)
+    LMRS_CASE(PRO_RMS_QUANT, EPI_SWIGLU)
+    LMRS_CASE(PRO_RMS_QUANT, EPI_GELU)
+    LMRS_CASE(PRO_RMS_QUANT, EPI_CLS)
+#undef LMRS_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint) {
+    if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
+    const int L = pick_L(a, epi);
+    const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, epi);
+    const size_t smem = gemv_smem(a, pro);
+    if (!a.q4) {
+        switch (L) {
+            case 8: return launch_LU<8, 16, false>(a, pro, epi, grid, smem, s);
+            case 16: return launch_LU<16, 16, false>(a, pro, epi, grid, smem, s);
+            case 32: return launch_LU<32, 16, false>(a, pro, epi, grid, smem, s);
+            default: return launch_LU<64, 16, false>(a, pro, epi, grid, smem, s);
+        }
+    } else {
+        switch (L) {
+            case 4: return launch_LU<4, 16, true>(a, pro, epi, grid, smem, s);
+            case 8: return launch_LU<8, 16, true>(a, pro, epi, grid, smem, s);
+            case 16: return launch_LU<16, 16, true>(a, pro, epi, grid, smem, s);
+            case 32: return launch_LU<32, 16, true>(a, pro, epi, grid, smem, s);
+            default: return launch_LU<64, 16, true>(a, pro, epi, grid, smem, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention for one new token: RoPE + scores + softmax + weighted V  (transformer.rs:443-544)
+// One workgroup per query head.  Softmax's sum and the V accumulation are sequential over t in the
+// reference and float addition is not associative, so they stay sequential here (one lane per
+// chain); everything order-free (scores across t, max, exp, divide, the hs output dims) is parallel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int hs = a.head_size, half = hs >> 1;
+    const int h = blockIdx.x, kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
+    const int kv_dim = a.n_kv_heads * hs;
+    const int pos = a.st->pos, T = pos + 1;
+    const int tid = threadIdx.x;
+    float* q = reinterpret_cast<float*>(smem);        // hs
+    float* kn = q + hs;                               // hs: rotated key of this position
+    float* att = kn + hs;                             // T
+    float* red = att + ((T + 3) & ~3);                // 8 floats of reduction scratch
+    const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
+
+    // RoPE (transformer.rs:480-491) with host-built (fcr, fci) table
+    for (int j = tid; j < half; j += kBlock) {
+        const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
+        const float fcr = cs.x, fci = cs.y;
+        {
+            const float v0 = a.q[h * hs + j], v1 = a.q[h * hs + j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            q[j] = a0 - a1; q[j + half] = b0 + b1;
+        }
+        {
+            const float v0 = a.k_raw[kvh * hs + j], v1 = a.k_raw[kvh * hs + j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            const float r0 = a0 - a1, r1 = b0 + b1;
+            kn[j] = r0; kn[j + half] = r1;
+            if (h % kv_mul == 0) {                   // one writer per kv head
+                a.k_cache[loff + (size_t)pos * kv_dim + kvh * hs + j] = r0;
+                a.k_cache[loff + (size_t)pos * kv_dim + kvh * hs + j + half] = r1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // scores (transformer.rs:507-529): one lane per t, sequential dot over the head dims
+    const float sqrt_hs = sqrtf((float)hs);
+    float lmax = __uint_as_float(0xff800000u);
+    for (int t = tid; t < T; t += kBlock) {
+        float score = 0.0f;
+        if (t == pos) {
+            for (int d = 0; d < hs; ++d) { const float pr = q[d] * kn[d]; score = score + pr; }
+        } else {
+            const float4* kr = reinterpret_cast<const float4*>(a.k_cache + loff + (size_t)t * kv_dim + kvh * hs);
+            for (int d4 = 0; d4 < (hs >> 2); ++d4) {
+                const float4 kk = kr[d4];
+                float pr = q[d4 * 4 + 0] * kk.x; score = score + pr;
+                pr = q[d4 * 4 + 1] * kk.y; score = score + pr;
+                pr = q[d4 * 4 + 2] * kk.z; score = score + pr;
+                pr = q[d4 * 4 + 3] * kk.w; score = score + pr;
+            }
+        }
+        score = score / sqrt_hs;
+        if (a.gemma) {                                 // transformer.rs:518-526
+            score = score / 50.0f;
+            score = (float)tanh((double)score);
+            score = score * 50.0f;
+            score = score + (((unsigned)(pos - t) <= 4096u) ? 0.0f : -2.3819763e38f);
+        }
+        att[t] = score;
+        lmax = fmaxf(lmax, score);
+    }
+    // softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int t = tid; t < T; t += kBlock) att[t] = expf_glibc(att[t] - mx);
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.0f;
+        for (int t = 0; t < T; ++t) sum = sum + att[t];
+        red[4] = sum;
+    }
+    __syncthreads();
+    const float sum = red[4];
+    for (int t = tid; t < T; t += kBlock) att[t] = att[t] / sum;
+    __syncthreads();
+
+    // weighted sum of values (transformer.rs:533-541): one lane per output dim, sequential over t
+    for (int d = tid; d < hs; d += kBlock) {
+        const float* vc = a.v_cache + loff + kvh * hs + d;
+        float o = 0.0f;
+        for (int t = 0; t < T; ++t) { const float pr = att[t] * vc[(size_t)t * kv_dim]; o = o + pr; }
+        a.out[h * hs + d] = o;
+    }
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    const size_t smem = (size_t)(2 * a.head_size + ((a.seq_len + 3) & ~3) + 8) * 4;
+    hipLaunchKernelGGL(attention_kernel, dim3(a.n_heads), dim3(kBlock), smem, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Embedding row (transformer.rs:324-332; quantization.rs:25-42) — dequantised on the fly, which is
+// bit-identical to reading the reference's load-time f32 copy of the table.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dequant_elem(const void* q, const float* s, int q4, size_t idx) {
+    if (!q4) return (float)reinterpret_cast<const int8_t*>(q)[idx] * s[idx / kGS];
+    const int8_t v = reinterpret_cast<const int8_t*>(q)[idx >> 1];
+    const int nib = (idx & 1) ? ((v >> 4) & 0x0F) - 8 : (v & 0x0F) - 8;
+    return (float)nib * s[idx / kGS];
+}
+
+__global__ void embed_kernel(const EmbedArgs a) {
+    const int pos = a.st->pos;
+    const uint32_t token = a.tokens[pos];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.dim; i += gridDim.x * blockDim.x) {
+        float v = dequant_elem(a.emb_q, a.emb_s, a.q4, (size_t)token * a.dim + i);
+        if (a.do_scale) v = v * a.scale;
+        a.x[i] = v;
+    }
+}
+
+hipError_t launch_embed(const EmbedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3((a.dim + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ void dequant_rows_kernel(const void* q, const float* s, int q4, const uint32_t* tokens, int dim, float* out) {
+    const uint32_t token = tokens[blockIdx.x];
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) out[(size_t)blockIdx.x * dim + i] = dequant_elem(q, s, q4, (size_t)token * dim + i);
+}
+
+hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint32_t* tokens, int n_tok, int dim, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(dequant_rows_kernel, dim3(n_tok), dim3(256), 0, st, q, s, q4, tokens, dim, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample_argmax (sampler.rs:29-41) over the per-workgroup partials, token feedback, position advance.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a) {
+    __shared__ float sv[kBlock];
+    __shared__ int si[kBlock];
+    float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
+    for (int i = threadIdx.x; i < a.n_part; i += kBlock) {
+        const float v = a.part_val[i]; const int idx = a.part_idx[i];
+        if (v > best || (v == best && idx < best_i)) { best = v; best_i = idx; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = best_i;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            const float ov = sv[threadIdx.x + off]; const int oi = si[threadIdx.x + off];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int win = si[0];
+        const float l0 = a.logits[0];
+        if (!(l0 == l0) || win == 0x7fffffff) win = 0;      // NaN at index 0 is never displaced (strict >)
+        const int pos = a.st->pos;
+        if (pos + 1 >= a.st->prompt_end) a.tokens[pos + 1] = (uint32_t)win;
+        a.st->pos = pos + 1;
+        a.st->step_count += 1;
+    }
+}
+
+hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thin kernels for the lmrs_op_* entry points: the same device functions as the fused path.
+// ------------------------------------------------------------------------------------------------
+template <bool Q4>
+__global__ __launch_bounds__(kBlock) void quantize_kernel(const float* x, void* q, float* s, int n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int8_t* xq = reinterpret_cast<int8_t*>(smem);
+    float* xs = reinterpret_cast<float*>(smem + ((n + 15) & ~15));
+    float4 v[kMaxP];
+    load_vec(v, x, n);
+    quantize_to_lds<Q4>(v, n, xq, xs, q, s);
+}
+
+hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st) {
+    if (n % kGS || n > kMaxP * 1024) return hipErrorInvalidValue;
+    const size_t smem = ((n + 15) & ~15) + (size_t)(n / kGS + 4) * 4;
+    if (q4) hipLaunchKernelGGL(quantize_kernel<true>, dim3(1), dim3(kBlock), smem, st, x, q, s, n);
+    else hipLaunchKernelGGL(quantize_kernel<false>, dim3(1), dim3(kBlock), smem, st, x, q, s, n);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void rmsnorm_kernel(const float* x, const float* w, float* o, int n, float eps, int add_unit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 v[kMaxP];
+    load_vec(v, x, n);
+    rmsnorm_inplace(v, n, w, eps, add_unit, reinterpret_cast<float*>(smem));
+    const int P = (n + 1023) >> 10;
+#pragma unroll
+    for (int i = 0; i < kMaxP; ++i)
+        if (i < P) {
+            const int e = i * 1024 + threadIdx.x * 4;
+            if (e < n) *reinterpret_cast<float4*>(o + e) = v[i];
+        }
+}
+
+hipError_t launch_rmsnorm(const float* x, const float* w, float* o, int n, float eps, int add_unit, hipStream_t st) {
+    if (n % 32 || n > kMaxP * 1024) return hipErrorInvalidValue;
+    const size_t smem = (size_t)(8 * (n / 8 + 4) + 4) * 4;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(kBlock), smem, st, x, w, o, n, eps, add_unit);
+    return hipGetLastError();
+}
+
+// softmax of functional.rs:122-140 on a vector in global memory (same code shape as attention_kernel)
+__global__ __launch_bounds__(kBlock) void softmax_kernel(float* x, int n) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    float lmax = __uint_as_float(0xff800000u);
+    for (int t = tid; t < n; t += kBlock) lmax = fmaxf(lmax, x[t]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int t = tid; t < n; t += kBlock) x[t] = expf_glibc(x[t] - mx);
+    __syncthreads();
+    if (tid == 0) {
+        float sum = 0.0f;
+        for (int t = 0; t < n; ++t) sum = sum + x[t];
+        red[4] = sum;
+    }
+    __syncthreads();
+    const float sum = red[4];
+    for (int t = tid; t < n; t += kBlock) x[t] = x[t] / sum;
+}
+
+hipError_t launch_softmax(float* x, int n, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_kernel, dim3(1), dim3(kBlock), 0, st, x, n);
+    return hipGetLastError();
+}
+
+__global__ void expf_kernel(const float* x, float* y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = expf_glibc(x[i]);
+}
+
+hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(expf_kernel, dim3(1024), dim3(256), 0, st, x, y, n);
+    return hipGetLastError();
+}
+
+}  // namespace lmrs

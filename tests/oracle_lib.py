@@ -46,6 +46,7 @@ def lib():
         L.lmrs_ref_generate_greedy.argtypes = [vp, vp, sz, u32, u32, vp, C.POINTER(C.c_double)]
         L.lmrs_ref_argmax.argtypes = [vp, sz]; L.lmrs_ref_argmax.restype = u32
         L.lmrs_ref_threads.restype = C.c_int
+        L.lmrs_ref_set_threads.argtypes = [C.c_int]; L.lmrs_ref_set_threads.restype = None
         L.lmrs_ref_kv.argtypes = [vp, C.c_int, u32, u32]; L.lmrs_ref_kv.restype = f32p
         L.lmrs_ref_op_rmsnorm.argtypes = [vp, vp, vp, sz, C.c_float, C.c_int]; L.lmrs_ref_op_rmsnorm.restype = None
         L.lmrs_ref_op_softmax.argtypes = [vp, sz]; L.lmrs_ref_op_softmax.restype = None
@@ -165,3 +166,7 @@ def expf(x: float) -> float:
 
 def threads() -> int:
     return lib().lmrs_ref_threads()
+
+
+def set_threads(n: int):
+    lib().lmrs_ref_set_threads(n)

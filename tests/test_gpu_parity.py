@@ -1,0 +1,226 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, through the C ABI, against the
+CPU oracle on the same seeded inputs.  Bar: bit-exact (integer work and, by construction of the
+kernels, every float too — see DESIGN.md "Parity")."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from tools import synth_lmrs as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lmrs_amd
+    return lmrs_amd
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bit_equal(a, b, what=""):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, what
+    ne = np.flatnonzero(bits(a) != bits(b)) if a.dtype == np.float32 else np.flatnonzero(a != b)
+    assert ne.size == 0, f"{what}: {ne.size}/{a.size} elements differ, first at {ne[:5]}: {a.ravel()[ne[:5]]} vs {b.ravel()[ne[:5]]}"
+
+
+# ------------------------------------------------------------------ L2 free functions
+def test_expf_matches_host_libm(L):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([
+        rng.uniform(-30, 0, 1 << 20), rng.uniform(-104, 89, 1 << 20), rng.uniform(-1e-3, 1e-3, 1 << 16),
+        np.array([0.0, -0.0, 88.0, 88.72, 88.73, 89.0, -87.3, -88.0, -103.0, -103.9, -104.0, -200.0, np.inf, -np.inf, 1e-40, -1e-40]),
+    ]).astype(np.float32)
+    dev = L.expf(xs)
+    host = np.array([O.expf(float(v)) for v in xs[: 1 << 16]], np.float32)
+    assert_bit_equal(dev[: 1 << 16], host, "expf (first 65536)")
+    # the rest through the oracle's softmax-free path: vectorised host expf via the oracle's op
+    tail = xs[-16:]
+    assert_bit_equal(dev[-16:], np.array([O.expf(float(v)) for v in tail], np.float32), "expf special values")
+    mid = xs[1 << 20: (1 << 20) + (1 << 16)]
+    assert_bit_equal(dev[1 << 20: (1 << 20) + (1 << 16)], np.array([O.expf(float(v)) for v in mid], np.float32), "expf wide range")
+
+
+@pytest.mark.parametrize("n", [128, 256, 2048, 3072, 8192, 9216])
+def test_quantize(L, n):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 3).astype(np.float32)
+    x[5] = 0.5 * np.abs(x[:128]).max()          # exercise round-half-away ties: x/scale = 63.5
+    if n >= 256:
+        x[128:256] = 0.0                         # all-zero group: scale 0, 0/0 = NaN -> 0
+    q, s = L.quantize(x)
+    qo, so = O.quantize(x)
+    assert_bit_equal(s, so, "q8 scales"); assert (q == qo).all()
+    q4, s4 = L.quantize_q4(x)
+    q4o, s4o = O.quantize_q4(x)
+    assert_bit_equal(s4, s4o, "q4 scales"); assert (q4 == q4o).all()
+
+
+@pytest.mark.parametrize("n,unit", [(128, False), (2048, False), (2304, True), (3072, False), (4096, True)])
+def test_rmsnorm(L, n, unit):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 2).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    assert_bit_equal(L.rmsnorm(x, w, 1e-5, unit), O.rmsnorm(x, w, 1e-5, unit), "rmsnorm")
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 64, 145, 1000, 8192])
+def test_softmax(L, n):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 4).astype(np.float32)
+    assert_bit_equal(L.softmax(x), O.softmax(x), "softmax")
+
+
+def _rand_q8(rng, o, n):
+    wq = rng.integers(-127, 128, size=o * n, dtype=np.int8)
+    ws = (rng.uniform(1e-4, 3e-3, size=o * n // 128)).astype(np.float32)
+    return wq, ws
+
+
+# the six GEMV shapes of config 2 (Llama-3.2-1B) + Llama-3B / Gemma-2B / ragged rows
+@pytest.mark.parametrize("n,o", [(2048, 2048), (2048, 512), (2048, 16384), (8192, 2048), (2048, 32064), (3072, 3072), (2304, 2048),
+                                 (9216, 2304), (128, 256), (256, 128), (2048, 4), (2048, 36)])
+def test_matmul_q8(L, n, o):
+    rng = np.random.default_rng(n * 7 + o)
+    wq, ws = _rand_q8(rng, o, n)
+    x = (rng.standard_normal(n) * 2).astype(np.float32)
+    xq, xs = O.quantize(x)
+    assert_bit_equal(L.matmul_q8(xq, xs, wq, ws, n, o), O.matmul_q8(xq, xs, wq, ws, n, o), f"matmul_q8 {n}->{o}")
+
+
+def test_matmul_q8_skips_tail_rows_like_the_reference(L):
+    # par_chunks_exact_mut(4): rows beyond o//4*4 are never written (functional.rs:179)
+    rng = np.random.default_rng(3)
+    n, o = 256, 10
+    wq, ws = _rand_q8(rng, o, n)
+    xq, xs = O.quantize(rng.standard_normal(n).astype(np.float32))
+    got = L.matmul_q8(xq, xs, wq, ws, n, o)
+    ref = O.matmul_q8(xq, xs, wq, ws, n, o)
+    assert_bit_equal(got, ref, "ragged o")
+    assert (got[8:] == 0).all()
+
+
+def test_matmul_q8_batched_rows(L):
+    rng = np.random.default_rng(4)
+    n, o, sl = 256, 64, 5
+    wq, ws = _rand_q8(rng, o, n)
+    x = rng.standard_normal(sl * n).astype(np.float32)
+    xq, xs = O.quantize(x)
+    assert_bit_equal(L.matmul_q8(xq, xs, wq, ws, n, o, sl=sl), O.matmul_q8(xq, xs, wq, ws, n, o, sl=sl), "matmul_q8 sl=5")
+
+
+@pytest.mark.parametrize("n,o", [(2304, 2048), (2304, 18432), (9216, 2304), (2048, 512), (128, 256), (256, 128), (8192, 2048), (3072, 100)])
+def test_matmul_q4(L, n, o):
+    rng = np.random.default_rng(n * 3 + o)
+    wq = rng.integers(0, 256, size=o * n // 2, dtype=np.uint8)
+    ws = (-rng.uniform(1e-3, 2e-2, size=o * n // 128)).astype(np.float32)
+    xq, xs = O.quantize_q4((rng.standard_normal(n) * 2).astype(np.float32))
+    assert_bit_equal(L.matmul_q4(xq, xs, wq, ws, n, o), O.matmul_q4(xq, xs, wq, ws, n, o), f"matmul_q4 {n}->{o}")
+
+
+# ------------------------------------------------------------------ whole path, golden fixtures
+GOLDEN = ["tiny_llama_q8", "tiny_llama_q4", "tiny_phi_q8"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+def test_golden_fixture_forward(L, golden_dir, name):
+    img = np.fromfile(os.path.join(golden_dir, name + ".lmrs"), np.uint8)
+    toks_gold = np.load(os.path.join(golden_dir, name + ".tokens.npy"))
+    logits_gold = np.load(os.path.join(golden_dir, name + ".logits.npy"))
+    m = L.Transformer(img); orc = O.Oracle(img)
+    assert m.bytes_consumed == orc.bytes_consumed == img.size
+    cfg_seed = {"tiny_llama_q8": ("tiny-llama", 7), "tiny_llama_q4": ("tiny-llama", 7), "tiny_phi_q8": ("tiny-phi", 9)}[name]
+    prompt = S.prompt_tokens(*cfg_seed[:1], 5, cfg_seed[1])
+    seq = list(prompt) + list(toks_gold[:-1])
+    lg = None
+    for pos, t in enumerate(seq):
+        lg = m.forward(int(t), pos).copy()
+        assert_bit_equal(lg, orc.forward(int(t), pos), f"{name} logits at pos {pos}")
+    assert_bit_equal(lg, logits_gold, f"{name} last-step logits vs committed golden")
+    m2 = L.Transformer(img)
+    assert (m2.generate_greedy(prompt, len(toks_gold)) == toks_gold).all()
+
+
+@pytest.mark.parametrize("cfg", ["mini-llama", "mini-llama3b", "mini-phi"])
+def test_mini_models_logits_bit_exact(L, cfg):
+    img = S.build_image(cfg, S.Q8_0, seed=11)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    prompt = S.prompt_tokens(cfg, 6, 11)
+    tok = None
+    for pos in range(20):
+        t = int(prompt[pos]) if pos < len(prompt) else tok
+        lg = m.forward(t, pos)
+        lo = orc.forward(t, pos)
+        assert_bit_equal(lg, lo, f"{cfg} logits at pos {pos}")
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+        assert m.forward_argmax(t, pos) == tok        # re-running a position is idempotent
+    for l in range(2):                                 # KV cache rows identical too
+        kv = m.args.n_kv_heads * m.args.head_size
+        assert kv == orc.args.n_kv_heads * orc.args.head_size
+
+
+def test_mini_q4_logits_bit_exact(L):
+    img = S.build_image("mini-llama", S.Q4_0, seed=12)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    prompt = S.prompt_tokens("mini-llama", 4, 12)
+    tok = None
+    for pos in range(12):
+        t = int(prompt[pos]) if pos < len(prompt) else tok
+        lo = orc.forward(t, pos)
+        assert_bit_equal(m.forward(t, pos), lo, f"q4 logits at pos {pos}")
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+
+
+def test_get_embeddings_and_fill_kv_cache(L):
+    img = S.build_image("mini-phi", S.Q8_0, seed=13)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    toks = S.prompt_tokens("mini-phi", 9, 13)
+    e_dev = m.get_embeddings(toks); e_ref = orc.get_embeddings(toks)
+    assert_bit_equal(e_dev, e_ref, "get_embeddings")
+    # empty input is legal in the reference (returns an empty Vec)
+    assert m.get_embeddings(np.zeros(0, np.uint32)).size == 0
+    a = e_dev.copy(); b = e_ref.copy()
+    assert m.fill_kv_cache(a, 3) == orc.fill_kv_cache(b, 3) == 3 + len(toks)
+    assert_bit_equal(a, b, "fill_kv_cache mutates the embeddings identically")
+    # decode continues on top of the batched prefill and stays bit-identical
+    assert_bit_equal(m.forward(5, 12), orc.forward(5, 12), "decode after fill_kv_cache")
+
+
+# ------------------------------------------------------------------ BASELINE config 2 at full size
+def test_llama_1b_q8_greedy_token_ids(L):
+    """BASELINE.json configs[0]/[1]: Llama-3.2-1B Q8_0, greedy, 16-token prompt + 128 generated tokens;
+    token IDs must be identical to the CPU path."""
+    cfg = "llama-3.2-1b"
+    img = S.build_image(cfg, S.Q8_0, seed=1234)
+    prompt = S.prompt_tokens(cfg, 16, 1234)
+    m = L.Transformer(img)
+    got, sec = m.generate_greedy(prompt, 128, timing=True)
+    orc = O.Oracle(img)
+    ref = orc.generate_greedy(prompt, 128)
+    assert (got == ref).all(), f"first mismatch at {int(np.flatnonzero(got != ref)[0])}"
+    # logits of one more step, bit for bit
+    lg = m.forward(int(ref[-1]), 16 + 127)
+    assert_bit_equal(lg, orc.forward(int(ref[-1]), 16 + 127), "1B logits at pos 143")
+    print(f"\n1B greedy 143 steps: {sec*1e3:.1f} ms on device = {143/sec:.0f} tok/s")
+
+
+# ------------------------------------------------------------------ error behaviour (reference: panics)
+def test_errors(L):
+    img = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "tiny_llama_q8.lmrs"), np.uint8)
+    bad = img.copy(); bad[0] = 0
+    with pytest.raises(L.LmrsError, match="lm.rs format"):
+        L.Transformer(bad)
+    with pytest.raises(L.LmrsError, match="truncated"):
+        L.Transformer(img[: img.size // 2])
+    m = L.Transformer(img)
+    with pytest.raises(L.LmrsError):
+        m.forward(m.args.vocab_size, 0)
+    with pytest.raises(L.LmrsError):
+        m.forward(0, m.args.seq_len)
+    with pytest.raises(L.LmrsError):
+        m.generate_greedy(np.zeros(0, np.uint32), 4)

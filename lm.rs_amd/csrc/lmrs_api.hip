@@ -158,17 +158,23 @@ GemvArgs cls_args(lmrs_ctx* c) {
     return g;
 }
 
-int enqueue_step(lmrs_ctx* c) {
+EmbedArgs embed_args(lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     EmbedArgs e{};
     e.emb_q = c->emb_q; e.emb_s = c->emb_s; e.q4 = c->q4; e.tokens = c->tokens; e.x = c->x; e.dim = a.dim;
     e.do_scale = a.model_type == LMRS_GEMMA; e.scale = sqrtf((float)a.dim); e.st = c->st;
-    HIP_OK(launch_embed(e, c->stream));
+    return e;
+}
+
+// One decode step minus the embedding of its input token: that row is produced by the previous step's
+// argmax kernel (or by launch_embed for the first step of a call), which saves a dependent launch per token.
+int enqueue_step(lmrs_ctx* c) {
+    const lmrs_args& a = c->args;
     for (uint32_t l = 0; l < a.n_layers; ++l) if (enqueue_layer(c, (int)l)) return -1;
     GemvArgs g = cls_args(c);                                   // final rmsnorm + quantize | classifier | argmax partials (:341-381)
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
     ArgmaxArgs m{};
-    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st;
+    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c);
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
 }
@@ -387,6 +393,7 @@ static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
     c->h_tok[0] = token;
     HIP_OK(hipMemcpyAsync(c->tokens + pos, c->h_tok, 4, hipMemcpyHostToDevice, c->stream));
     if (set_state(c, pos, 0)) return -1;
+    HIP_OK(launch_embed(embed_args(c), c->stream));
     HIP_OK(hipGraphLaunch(c->g_step, c->stream));
     return 0;
 }
@@ -454,6 +461,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     HIP_OK(hipMemcpyAsync(c->tokens + start_pos, c->h_tok, n_prompt * 4, hipMemcpyHostToDevice, c->stream));
     if (set_state(c, start_pos, start_pos + (uint32_t)n_prompt)) return -1;
     HIP_OK(hipEventRecord(c->ev0, c->stream));
+    HIP_OK(launch_embed(embed_args(c), c->stream));
     for (size_t s = 0; s < steps; ++s) HIP_OK(hipGraphLaunch(c->g_step, c->stream));
     HIP_OK(hipEventRecord(c->ev1, c->stream));
     if (n_new) HIP_OK(hipMemcpyAsync(c->h_tok, c->tokens + start_pos + n_prompt, (size_t)n_new * 4, hipMemcpyDeviceToHost, c->stream));
@@ -491,7 +499,7 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
             default: g = cls_args(c); pro = PRO_RMS_QUANT; epi = EPI_CLS; break;
         }
     };
-    if (set_state(c, 0, 0)) return -1;
+    if (set_state(c, a.seq_len - 1, 0)) return -1;      // the V row the qkv epilogue scribbles on: the last one
     for (int it = -1; it < iters; ++it) {              // it == -1: untimed warm-up pass
         int i = 0;
         for (int l = 0; l <= nl; ++l)
@@ -526,7 +534,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = 1 + 5 * (int)a.n_layers + 2;
+    if (n_launches) *n_launches = 5 * (int)a.n_layers + 2;
     return 0;
 }
 

@@ -42,6 +42,7 @@ struct AttnArgs {
     const float* rope;       // [seq_len][head_size/2][2] = (fcr, fci)
     float* out;              // att_dim
     int n_heads, n_kv_heads, head_size, seq_len, layer, gemma;
+    int chunk;               // timesteps staged through LDS at a time (set by launch_attention)
     const DevState* st;
 };
 
@@ -56,6 +57,7 @@ struct ArgmaxArgs {
     const float* part_val; const int* part_idx; int n_part;
     const float* logits;
     uint32_t* tokens; DevState* st;
+    EmbedArgs emb;           // the winner's (or the next prompt token's) embedding row is written to emb.x
 };
 
 // launches (all asynchronous on `s`)

@@ -41,18 +41,21 @@ constexpr int kGS = 128;             // quantisation group size (the reference e
 
 // Thread t owns elements e = i*1024 + 4t .. +3 for i = 0..P-1  (P = ceil(n / 1024)), so that 32
 // consecutive lanes own one 128-element quantisation group.
-constexpr int kMaxP = 10;            // n <= 10240
+constexpr int kMaxP = 10;            // n <= 10240 (NP, the per-lane float4 count, is a template parameter <= kMaxP)
 
 // RMSNorm (functional.rs:48-78) of x[n] (held in v[]), result written back into v[].
+// wv[] = the norm weights of the same elements (loaded by the caller, early, so that no late global
+// load sits behind the weight stream in the in-order vmcnt queue).
 // scratch: (8 * (n/8 + 4) + 1) floats of LDS.
-__device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[kMaxP], int n, const float* __restrict__ w, float eps,
+template <int NP>
+__device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[NP], const float4 (&wv)[NP], int n, float eps,
                                                 int add_unit, float* scratch) {
     const int t = threadIdx.x;
     const int P = (n + 1023) >> 10;
     const int JP = (n >> 3) + 4;                 // padded row length of the transposed square table
     // squares, transposed: T[k][j] = x[8j+k]^2 so that lane k walks j contiguously
 #pragma unroll
-    for (int i = 0; i < kMaxP; ++i) {
+    for (int i = 0; i < NP; ++i) {
         if (i < P) {
             const int e = i * 1024 + t * 4;
             if (e < n) {
@@ -66,16 +69,27 @@ __device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[kMaxP], int n, const
     }
     __syncthreads();
     if (t < 64) {
-        // lanes 0..7: the 8 strided partial sums, each a sequential chain over j (ss_sim += x*x)
+        // lanes 0..7: the 8 strided partial sums, each a sequential chain over j (ss_sim += x*x).
+        // The adds are inherently serial (float addition is not associative); the LDS reads are not, so
+        // they are issued 8 x 16 B ahead of the chain (two register batches, ping-pong).
         float p = 0.0f;
         if (t < 8) {
             const float4* row = reinterpret_cast<const float4*>(scratch + t * JP);
-            const int nj4 = n >> 5;                          // (n/8)/4
-            for (int j = 0; j < nj4; ++j) {
-                const float4 s4 = row[j];
-                p = p + s4.x; p = p + s4.y; p = p + s4.z; p = p + s4.w;
+            const int nj4 = n >> 5;                          // (n/8)/4 float4 per row  (n % 32 == 0)
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);   // p >= +0, so p + 0 == p exactly: padding is free
+            float4 A[8], B[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) A[u] = u < nj4 ? row[u] : z4;
+            for (int j0 = 0; j0 < nj4; j0 += 16) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) B[u] = (j0 + 8 + u) < nj4 ? row[j0 + 8 + u] : z4;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) A[u] = (j0 + 16 + u) < nj4 ? row[j0 + 16 + u] : z4;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
             }
-            for (int j = nj4 * 4; j < (n >> 3); ++j) p = p + scratch[t * JP + j];
         }
         const float p0 = __shfl(p, 0), p1 = __shfl(p, 1), p2 = __shfl(p, 2), p3 = __shfl(p, 3);
         const float p4 = __shfl(p, 4), p5 = __shfl(p, 5), p6 = __shfl(p, 6), p7 = __shfl(p, 7);
@@ -90,18 +104,17 @@ __device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[kMaxP], int n, const
     __syncthreads();
     const float ss = scratch[8 * JP];
 #pragma unroll
-    for (int i = 0; i < kMaxP; ++i) {
+    for (int i = 0; i < NP; ++i) {
         if (i < P) {
             const int e = i * 1024 + t * 4;
             if (e < n) {
-                const float4 wv = *reinterpret_cast<const float4*>(w + e);
                 float4 o;
                 if (add_unit) {
-                    o.x = (1.0f + wv.x) * (ss * v[i].x); o.y = (1.0f + wv.y) * (ss * v[i].y);
-                    o.z = (1.0f + wv.z) * (ss * v[i].z); o.w = (1.0f + wv.w) * (ss * v[i].w);
+                    o.x = (1.0f + wv[i].x) * (ss * v[i].x); o.y = (1.0f + wv[i].y) * (ss * v[i].y);
+                    o.z = (1.0f + wv[i].z) * (ss * v[i].z); o.w = (1.0f + wv[i].w) * (ss * v[i].w);
                 } else {
-                    o.x = wv.x * (ss * v[i].x); o.y = wv.y * (ss * v[i].y);
-                    o.z = wv.z * (ss * v[i].z); o.w = wv.w * (ss * v[i].w);
+                    o.x = wv[i].x * (ss * v[i].x); o.y = wv[i].y * (ss * v[i].y);
+                    o.z = wv[i].z * (ss * v[i].z); o.w = wv[i].w * (ss * v[i].w);
                 }
                 v[i] = o;
             }
@@ -114,12 +127,12 @@ __device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[kMaxP], int n, const
 //   Q4_0: xq holds the UNPACKED signed nibble values (q-8), de-interleaved per 8 elements as
 //         [e0 e2 e4 e6 | e1 e3 e5 e7] so that they line up with (w & 0x0F0F0F0F) / (w >> 4 & ...).
 // If gq/gs_out are non-null (lmrs_op_quantize), block 0 also writes the reference's packed form.
-template <bool Q4>
-__device__ __forceinline__ void quantize_to_lds(const float4 (&v)[kMaxP], int n, int8_t* xq, float* xs, void* gq, float* gs_out) {
+template <bool Q4, int NP>
+__device__ __forceinline__ void quantize_to_lds(const float4 (&v)[NP], int n, int8_t* xq, float* xs, void* gq, float* gs_out) {
     const int t = threadIdx.x;
     const int P = (n + 1023) >> 10;
 #pragma unroll
-    for (int i = 0; i < kMaxP; ++i) {
+    for (int i = 0; i < NP; ++i) {
         if (i < P) {
             const int e = i * 1024 + t * 4;
             const bool live = e < n;
@@ -161,11 +174,12 @@ __device__ __forceinline__ void quantize_to_lds(const float4 (&v)[kMaxP], int n,
     }
 }
 
-__device__ __forceinline__ void load_vec(float4 (&v)[kMaxP], const float* __restrict__ x, int n) {
+template <int NP>
+__device__ __forceinline__ void load_vec(float4 (&v)[NP], const float* __restrict__ x, int n) {
     const int t = threadIdx.x;
     const int P = (n + 1023) >> 10;
 #pragma unroll
-    for (int i = 0; i < kMaxP; ++i) {
+    for (int i = 0; i < NP; ++i) {
         if (i < P) {
             const int e = i * 1024 + t * 4;
             if (e < n) v[i] = *reinterpret_cast<const float4*>(x + e);
@@ -209,7 +223,7 @@ __device__ __forceinline__ int group_partial_dot(const i32x4& w, const int8_t* x
 
 // L lanes per row, U steps in flight, PRO/EPI fused stages, Q4 = packed-nibble weights.
 // CL = lanes covering one quantisation group: 8 (Q8_0: 8 x 16 B = 128 B) or 4 (Q4_0: 4 x 16 B = 64 B).
-template <int L, int U, int PRO, int EPI, bool Q4>
+template <int L, int U, int NP, int PRO, int EPI, bool Q4>
 __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CL = Q4 ? 4 : 8;
@@ -219,29 +233,6 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     float* xs = reinterpret_cast<float*>(smem + ((n + 15) & ~15));      // G floats
     float* scratch = xs + ((G + 3) & ~3);
 
-    // ---------------- prologue: build the quantised activation vector in LDS
-    if constexpr (PRO == PRO_PREQ) {
-        if constexpr (!Q4) {
-            for (int e = threadIdx.x * 16; e < n; e += kBlock * 16)
-                *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
-        } else {
-            const uint8_t* src = reinterpret_cast<const uint8_t*>(a.xq_in);
-            for (int b = threadIdx.x * 4; b < n / 2; b += kBlock * 4) {   // 4 packed bytes = one octet of elements
-                const unsigned v = *reinterpret_cast<const unsigned*>(src + b);
-                *reinterpret_cast<int*>(xq + 2 * b) = nib_signed(v);
-                *reinterpret_cast<int*>(xq + 2 * b + 4) = nib_signed(v >> 4);
-            }
-        }
-        for (int g = threadIdx.x; g < G; g += kBlock) xs[g] = a.xs_in[g];
-    } else {
-        float4 v[kMaxP];
-        load_vec(v, a.xin, n);
-        if constexpr (PRO == PRO_RMS_QUANT) rmsnorm_inplace(v, n, a.rms_w, a.eps, a.add_unit, scratch);
-        quantize_to_lds<Q4>(v, n, xq, xs, nullptr, nullptr);
-    }
-    __syncthreads();
-
-    // ---------------- main loop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane % L;                       // lane within the row
     constexpr int RW = 64 / L;                    // rows per wave
@@ -251,23 +242,60 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     const int o = a.o;
     const int n_pass = (o + RB - 1) / RB;
 
+    // ---------------- issue order matters: vmcnt retires in order, so the (small, latency-critical)
+    // activation loads go first, then the first U weight steps of this workgroup's first rows; the
+    // prologue's arithmetic then runs underneath the weight stream's HBM latency.
+    float4 v[NP], nw[NP];
+    if constexpr (PRO != PRO_PREQ) {
+        load_vec(v, a.xin, n);
+        if constexpr (PRO == PRO_RMS_QUANT) load_vec(nw, a.rms_w, n);
+    }
+    i32x4 w[U]; float sc[U];
+    auto issue = [&](int pass, int k0) __attribute__((always_inline)) {
+        int row = pass * RB + wave * RW + lane / L;
+        row = row < o ? row : o - 1;
+        const i32x4* wrow = reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(a.wq) + (size_t)row * row_bytes) + r;
+        const float* srow = a.ws + (size_t)row * G;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k0 + u < steps) {
+                w[u] = ld_nt(wrow + (k0 + u) * L);
+                sc[u] = srow[((k0 + u) * L + r) / CL];
+            }
+    };
+    if ((int)blockIdx.x < n_pass) issue(blockIdx.x, 0);
+
+    // ---------------- prologue: build the quantised activation vector in LDS
+    if constexpr (PRO == PRO_PREQ) {
+        if constexpr (!Q4) {
+            for (int e = threadIdx.x * 16; e < n; e += kBlock * 16)
+                *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
+        } else {
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(a.xq_in);
+            for (int b = threadIdx.x * 4; b < n / 2; b += kBlock * 4) {   // 4 packed bytes = one octet of elements
+                const unsigned pk = *reinterpret_cast<const unsigned*>(src + b);
+                *reinterpret_cast<int*>(xq + 2 * b) = nib_signed(pk);
+                *reinterpret_cast<int*>(xq + 2 * b + 4) = nib_signed(pk >> 4);
+            }
+        }
+        for (int g = threadIdx.x; g < G; g += kBlock) xs[g] = a.xs_in[g];
+    } else {
+        if constexpr (PRO == PRO_RMS_QUANT) rmsnorm_inplace(v, nw, n, a.eps, a.add_unit, scratch);
+        quantize_to_lds<Q4, NP>(v, n, xq, xs, nullptr, nullptr);
+    }
+    __syncthreads();
+
+    // ---------------- main loop
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;   // EPI_CLS
+    bool preloaded = true;
 
     for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
         const int row = pass * RB + wave * RW + lane / L;
         const bool valid = row < o;
-        const int rowc = valid ? row : o - 1;
-        const i32x4* wrow = reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(a.wq) + (size_t)rowc * row_bytes) + r;
-        const float* srow = a.ws + (size_t)rowc * G;
         float acc = 0.0f;
         for (int k0 = 0; k0 < steps; k0 += U) {
-            i32x4 w[U]; float sc[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (k0 + u < steps) {
-                    w[u] = ld_nt(wrow + (k0 + u) * L);
-                    sc[u] = srow[((k0 + u) * L + r) / CL];
-                }
+            if (!preloaded) issue(pass, k0);
+            preloaded = false;
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (k0 + u < steps) {
@@ -372,12 +400,12 @@ int gemv_grid(const GemvArgs& a, int epi) {
     return n_pass < cap ? n_pass : cap;
 }
 
-template <int L, int U, bool Q4>
+template <int L, int U, int NP, bool Q4>
 static hipError_t launch_LU(const GemvArgs& a, int pro, int epi, int grid, size_t smem, hipStream_t s) {
-#define LMRS_CASE(P, E)                                                                       \
-    if (pro == P && epi == E) {                                                               \
-        hipLaunchKernelGGL((gemv_kernel<L, U, P, E, Q4>), dim3(grid), dim3(kBlock), smem, s, a); \
-        return hipGetLastError();                                                             \
+#define LMRS_CASE(P, E)                                                                           \
+    if (pro == P && epi == E) {                                                                   \
+        hipLaunchKernelGGL((gemv_kernel<L, U, NP, P, E, Q4>), dim3(grid), dim3(kBlock), smem, s, a); \
+        return hipGetLastError();                                                                 \
     }
     LMRS_CASE(PRO_PREQ, EPI_STORE)
     LMRS_CASE(PRO_QUANT, EPI_STORE)
@@ -391,49 +419,83 @@ static hipError_t launch_LU(const GemvArgs& a, int pro, int epi, int grid, size_
     return hipErrorInvalidValue;
 }
 
+// (L, NP) classes that get their own instantiation; NP = float4 per lane of the activation vector
+// (ceil(n/1024)): keeping it a compile-time constant keeps the prologue's registers proportional to n.
 hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint) {
     if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
     const int L = pick_L(a, epi);
+    const int P = (a.n + 1023) / 1024;
     const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, epi);
     const size_t smem = gemv_smem(a, pro);
+#define LMRS_TRY(LL, PP, QQ) if (L == LL && P <= PP) return launch_LU<LL, 16, PP, QQ>(a, pro, epi, grid, smem, s);
     if (!a.q4) {
-        switch (L) {
-            case 8: return launch_LU<8, 16, false>(a, pro, epi, grid, smem, s);
-            case 16: return launch_LU<16, 16, false>(a, pro, epi, grid, smem, s);
-            case 32: return launch_LU<32, 16, false>(a, pro, epi, grid, smem, s);
-            default: return launch_LU<64, 16, false>(a, pro, epi, grid, smem, s);
-        }
+        LMRS_TRY(8, 1, false) LMRS_TRY(8, 2, false) LMRS_TRY(8, 10, false)
+        LMRS_TRY(16, 3, false) LMRS_TRY(16, 4, false) LMRS_TRY(16, 10, false)
+        LMRS_TRY(32, 8, false) LMRS_TRY(32, 10, false)
+        LMRS_TRY(64, 10, false)
     } else {
-        switch (L) {
-            case 4: return launch_LU<4, 16, true>(a, pro, epi, grid, smem, s);
-            case 8: return launch_LU<8, 16, true>(a, pro, epi, grid, smem, s);
-            case 16: return launch_LU<16, 16, true>(a, pro, epi, grid, smem, s);
-            case 32: return launch_LU<32, 16, true>(a, pro, epi, grid, smem, s);
-            default: return launch_LU<64, 16, true>(a, pro, epi, grid, smem, s);
-        }
+        LMRS_TRY(4, 2, true) LMRS_TRY(4, 10, true) LMRS_TRY(8, 3, true) LMRS_TRY(8, 10, true)
+        LMRS_TRY(16, 8, true) LMRS_TRY(16, 10, true) LMRS_TRY(32, 10, true) LMRS_TRY(64, 10, true)
     }
+#undef LMRS_TRY
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Attention for one new token: RoPE + scores + softmax + weighted V  (transformer.rs:443-544)
 // One workgroup per query head.  Softmax's sum and the V accumulation are sequential over t in the
-// reference and float addition is not associative, so they stay sequential here (one lane per
-// chain); everything order-free (scores across t, max, exp, divide, the hs output dims) is parallel.
+// reference and float addition is not associative, so each stays one serial chain on one lane;
+// everything order-free (scores across t, max, exp, divide, the hs output dims) is parallel.
+// The K and V rows of the head are staged through LDS in chunks of CH timesteps (CH*hs = 16384 floats):
+// all 256 lanes issue their global loads up front (K and V of the first chunk together, before RoPE),
+// so the chains never wait on a global load; the next chunk's loads are in flight while the current one
+// is consumed.
 // ------------------------------------------------------------------------------------------------
+constexpr int kAttF4 = 16;           // float4 per lane per chunk: CH * hs / 4 / 256 <= 16
+
+// rows t0 .. t0+ct of one kv head (row stride kv_dim floats) -> registers, 16 B per lane per load, coalesced per row
+__device__ __forceinline__ void att_gload(float4 (&rg)[kAttF4], const float* __restrict__ base, int t0, int T, int CH, int hs4, int kv_dim) {
+    const int ct = (T - t0) < CH ? (T - t0) : CH, nf = ct * hs4;
+#pragma unroll
+    for (int i = 0; i < kAttF4; ++i) {
+        const int f = (int)threadIdx.x + i * kBlock;
+        const int row = f / hs4, c4 = f - row * hs4;
+        rg[i] = f < nf ? *reinterpret_cast<const float4*>(base + (size_t)(t0 + row) * kv_dim + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void att_tstore(const float4 (&rg)[kAttF4], float* tile, int t0, int T, int CH, int hs4, int RS, int skip_t) {
+    const int ct = (T - t0) < CH ? (T - t0) : CH, nf = ct * hs4;
+#pragma unroll
+    for (int i = 0; i < kAttF4; ++i) {
+        const int f = (int)threadIdx.x + i * kBlock;
+        const int row = f / hs4, c4 = f - row * hs4;
+        if (f < nf && t0 + row != skip_t) *reinterpret_cast<float4*>(tile + row * RS + c4 * 4) = rg[i];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int hs = a.head_size, half = hs >> 1;
+    const int hs = a.head_size, half = hs >> 1, hs4 = hs >> 2, RS = hs + 4;
     const int h = blockIdx.x, kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const int kv_dim = a.n_kv_heads * hs;
     const int pos = a.st->pos, T = pos + 1;
     const int tid = threadIdx.x;
+    const int CH = a.chunk;
     float* q = reinterpret_cast<float*>(smem);        // hs
     float* kn = q + hs;                               // hs: rotated key of this position
-    float* att = kn + hs;                             // T
-    float* red = att + ((T + 3) & ~3);                // 8 floats of reduction scratch
+    float* red = kn + hs;                             // 16 floats of reduction scratch
+    float* tile = red + 16;                           // CH rows of RS floats (RS = hs + 4: conflict-free float4 row reads)
+    float* att = tile + (size_t)CH * RS;              // T
     const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
+    const int nchunks = (T + CH - 1) / CH;
 
-    // RoPE (transformer.rs:480-491) with host-built (fcr, fci) table
+    float4 kreg[kAttF4], vreg[kAttF4];
+    const float* kbase = a.k_cache + loff + kvh * hs;
+    const float* vbase = a.v_cache + loff + kvh * hs;
+    att_gload(kreg, kbase, 0, T, CH, hs4, kv_dim);   // row `pos` of K is not in the cache yet (patched from kn below); its load is harmless
+    att_gload(vreg, vbase, 0, T, CH, hs4, kv_dim);   // row `pos` of V was stored by the QKV kernel
+
+    // RoPE (transformer.rs:480-491) with the host-built (fcr, fci) table
     for (int j = tid; j < half; j += kBlock) {
         const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
         const float fcr = cs.x, fci = cs.y;
@@ -458,29 +520,49 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     // scores (transformer.rs:507-529): one lane per t, sequential dot over the head dims
     const float sqrt_hs = sqrtf((float)hs);
     float lmax = __uint_as_float(0xff800000u);
-    for (int t = tid; t < T; t += kBlock) {
-        float score = 0.0f;
-        if (t == pos) {
-            for (int d = 0; d < hs; ++d) { const float pr = q[d] * kn[d]; score = score + pr; }
-        } else {
-            const float4* kr = reinterpret_cast<const float4*>(a.k_cache + loff + (size_t)t * kv_dim + kvh * hs);
-            for (int d4 = 0; d4 < (hs >> 2); ++d4) {
-                const float4 kk = kr[d4];
-                float pr = q[d4 * 4 + 0] * kk.x; score = score + pr;
-                pr = q[d4 * 4 + 1] * kk.y; score = score + pr;
-                pr = q[d4 * 4 + 2] * kk.z; score = score + pr;
-                pr = q[d4 * 4 + 3] * kk.w; score = score + pr;
+    for (int c = 0; c < nchunks; ++c) {
+        const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
+        att_tstore(kreg, tile, t0, T, CH, hs4, RS, pos);
+        if (pos >= t0 && pos < t0 + ct && tid < hs4)
+            *reinterpret_cast<float4*>(tile + (pos - t0) * RS + tid * 4) = *reinterpret_cast<const float4*>(kn + tid * 4);
+        __syncthreads();
+        if (c + 1 < nchunks) att_gload(kreg, kbase, t0 + CH, T, CH, hs4, kv_dim);
+        if (tid < ct) {
+            const float4* kr = reinterpret_cast<const float4*>(tile + tid * RS);
+            float score = 0.0f;
+            for (int d4 = 0; d4 < hs4; d4 += 4) {              // hs % 16 == 0 is not required: guarded below
+                float4 k0 = kr[d4], k1 = d4 + 1 < hs4 ? kr[d4 + 1] : k0, k2 = d4 + 2 < hs4 ? kr[d4 + 2] : k0, k3 = d4 + 3 < hs4 ? kr[d4 + 3] : k0;
+                const float4 q0 = *reinterpret_cast<const float4*>(q + d4 * 4);
+                float pr;
+                pr = q0.x * k0.x; score = score + pr; pr = q0.y * k0.y; score = score + pr;
+                pr = q0.z * k0.z; score = score + pr; pr = q0.w * k0.w; score = score + pr;
+                if (d4 + 1 < hs4) {
+                    const float4 q1 = *reinterpret_cast<const float4*>(q + d4 * 4 + 4);
+                    pr = q1.x * k1.x; score = score + pr; pr = q1.y * k1.y; score = score + pr;
+                    pr = q1.z * k1.z; score = score + pr; pr = q1.w * k1.w; score = score + pr;
+                }
+                if (d4 + 2 < hs4) {
+                    const float4 q2 = *reinterpret_cast<const float4*>(q + d4 * 4 + 8);
+                    pr = q2.x * k2.x; score = score + pr; pr = q2.y * k2.y; score = score + pr;
+                    pr = q2.z * k2.z; score = score + pr; pr = q2.w * k2.w; score = score + pr;
+                }
+                if (d4 + 3 < hs4) {
+                    const float4 q3 = *reinterpret_cast<const float4*>(q + d4 * 4 + 12);
+                    pr = q3.x * k3.x; score = score + pr; pr = q3.y * k3.y; score = score + pr;
+                    pr = q3.z * k3.z; score = score + pr; pr = q3.w * k3.w; score = score + pr;
+                }
             }
+            score = score / sqrt_hs;
+            if (a.gemma) {                                 // transformer.rs:518-526
+                score = score / 50.0f;
+                score = (float)tanh((double)score);
+                score = score * 50.0f;
+                score = score + (((unsigned)(pos - (t0 + tid)) <= 4096u) ? 0.0f : -2.3819763e38f);
+            }
+            att[t0 + tid] = score;
+            lmax = fmaxf(lmax, score);
         }
-        score = score / sqrt_hs;
-        if (a.gemma) {                                 // transformer.rs:518-526
-            score = score / 50.0f;
-            score = (float)tanh((double)score);
-            score = score * 50.0f;
-            score = score + (((unsigned)(pos - t) <= 4096u) ? 0.0f : -2.3819763e38f);
-        }
-        att[t] = score;
-        lmax = fmaxf(lmax, score);
+        __syncthreads();
     }
     // softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
 #pragma unroll
@@ -492,25 +574,63 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     __syncthreads();
     if (tid == 0) {
         float sum = 0.0f;
-        for (int t = 0; t < T; ++t) sum = sum + att[t];
+        int t = 0;
+        for (; t + 16 <= T; t += 16) {                     // 16 LDS reads in flight per batch of 16 serial adds
+            float e[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) e[u] = att[t + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sum = sum + e[u];
+        }
+        for (; t < T; ++t) sum = sum + att[t];
         red[4] = sum;
     }
     __syncthreads();
     const float sum = red[4];
     for (int t = tid; t < T; t += kBlock) att[t] = att[t] / sum;
-    __syncthreads();
+    // (the barrier inside the chunk loop below orders these writes before the reads)
 
     // weighted sum of values (transformer.rs:533-541): one lane per output dim, sequential over t
-    for (int d = tid; d < hs; d += kBlock) {
-        const float* vc = a.v_cache + loff + kvh * hs + d;
-        float o = 0.0f;
-        for (int t = 0; t < T; ++t) { const float pr = att[t] * vc[(size_t)t * kv_dim]; o = o + pr; }
-        a.out[h * hs + d] = o;
+    float o = 0.0f;
+    for (int c = 0; c < nchunks; ++c) {
+        const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
+        att_tstore(vreg, tile, t0, T, CH, hs4, RS, -1);
+        __syncthreads();
+        if (c + 1 < nchunks) att_gload(vreg, vbase, t0 + CH, T, CH, hs4, kv_dim);
+        if (tid < hs) {
+            const float* vc = tile + tid;
+            const float* at = att + t0;
+            int t = 0;
+            for (; t + 8 <= ct; t += 8) {
+                float vv[8], aa[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { vv[u] = vc[(t + u) * RS]; aa[u] = at[t + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const float pr = aa[u] * vv[u]; o = o + pr; }
+            }
+            for (; t < ct; ++t) { const float pr = at[t] * vc[t * RS]; o = o + pr; }
+        }
+        __syncthreads();
     }
+    if (tid < hs) a.out[h * hs + tid] = o;
 }
 
-hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    const size_t smem = (size_t)(2 * a.head_size + ((a.seq_len + 3) & ~3) + 8) * 4;
+int attention_chunk(int head_size) {
+    int ch = (16384 / head_size) & ~31;
+    if (ch > 256) ch = 256;                 // one row per lane in the score phase
+    return ch < 32 ? 32 : ch;
+}
+
+hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
+    AttnArgs a = a0;
+    a.chunk = attention_chunk(a.head_size);
+    if (a.head_size > 256 || a.head_size % 4 || a.chunk * (a.head_size / 4) > kAttF4 * kBlock) return hipErrorInvalidValue;
+    const size_t smem = (size_t)(2 * a.head_size + 16 + (size_t)a.chunk * (a.head_size + 4) + ((a.seq_len + 3) & ~3)) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(attention_kernel, dim3(a.n_heads), dim3(kBlock), smem, s, a);
     return hipGetLastError();
 }
@@ -557,6 +677,7 @@ hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint
 __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a) {
     __shared__ float sv[kBlock];
     __shared__ int si[kBlock];
+    __shared__ uint32_t s_next;
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
     for (int i = threadIdx.x; i < a.n_part; i += kBlock) {
         const float v = a.part_val[i]; const int idx = a.part_idx[i];
@@ -576,9 +697,20 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
         const float l0 = a.logits[0];
         if (!(l0 == l0) || win == 0x7fffffff) win = 0;      // NaN at index 0 is never displaced (strict >)
         const int pos = a.st->pos;
-        if (pos + 1 >= a.st->prompt_end) a.tokens[pos + 1] = (uint32_t)win;
+        uint32_t next = (uint32_t)win;
+        if (pos + 1 >= a.st->prompt_end) a.tokens[pos + 1] = next;   // chat.rs:188-193: sampler output ignored while the prompt lasts
+        else next = a.tokens[pos + 1];
         a.st->pos = pos + 1;
         a.st->step_count += 1;
+        s_next = next;
+    }
+    __syncthreads();
+    // embedding row of the next input token (transformer.rs:324-332) for the next replay of the step graph
+    const uint32_t token = s_next;
+    for (int i = threadIdx.x; i < a.emb.dim; i += kBlock) {
+        float v = dequant_elem(a.emb.emb_q, a.emb.emb_s, a.emb.q4, (size_t)token * a.emb.dim + i);
+        if (a.emb.do_scale) v = v * a.emb.scale;
+        a.emb.x[i] = v;
     }
 }
 
@@ -597,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void quantize_kernel(const float* x, void* 
     float* xs = reinterpret_cast<float*>(smem + ((n + 15) & ~15));
     float4 v[kMaxP];
     load_vec(v, x, n);
-    quantize_to_lds<Q4>(v, n, xq, xs, q, s);
+    quantize_to_lds<Q4, kMaxP>(v, n, xq, xs, q, s);
 }
 
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st) {
@@ -610,9 +742,10 @@ hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hip
 
 __global__ __launch_bounds__(kBlock) void rmsnorm_kernel(const float* x, const float* w, float* o, int n, float eps, int add_unit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 v[kMaxP];
+    float4 v[kMaxP], nw[kMaxP];
     load_vec(v, x, n);
-    rmsnorm_inplace(v, n, w, eps, add_unit, reinterpret_cast<float*>(smem));
+    load_vec(nw, w, n);
+    rmsnorm_inplace(v, nw, n, eps, add_unit, reinterpret_cast<float*>(smem));
     const int P = (n + 1023) >> 10;
 #pragma unroll
     for (int i = 0; i < kMaxP; ++i)

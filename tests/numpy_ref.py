@@ -1,0 +1,258 @@
+"""Independent numpy transcription of the reference's forward pass (TEST INFRASTRUCTURE).
+
+Written from the Rust sources (reference src/transformer.rs:316-657, src/functional.rs:48-250,
+src/quantization.rs:25-95) separately from oracle/lmrs_oracle.c, in a different style (vectorised
+numpy with explicit float32 rounding points), to catch transcription slips in the C oracle.  Only
+small models: it is slow.  exp/cos/sin/pow go through the C library (ctypes libm), as Rust's do.
+"""
+import ctypes
+import ctypes.util
+import math
+import struct
+
+import numpy as np
+
+F = np.float32
+_libm = ctypes.CDLL(ctypes.util.find_library("m"))
+for _n in ("expf", "cosf", "sinf", "logf", "sqrtf"):
+    getattr(_libm, _n).restype = ctypes.c_float
+    getattr(_libm, _n).argtypes = [ctypes.c_float]
+_libm.powf.restype = ctypes.c_float
+_libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+_libm.tanh.restype = ctypes.c_double
+_libm.tanh.argtypes = [ctypes.c_double]
+
+
+def expf(x):
+    return F(_libm.expf(float(x)))
+
+
+def reduce_add8(v):          # wide f32x8::reduce_add, AVX path
+    return F(F(F(v[0] + v[4]) + F(v[2] + v[6])) + F(F(v[1] + v[5]) + F(v[3] + v[7])))
+
+
+def rmsnorm(x, w, eps, add_unit):
+    n = x.size
+    acc = np.zeros(8, F)
+    xs = x.reshape(-1, 8)
+    for j in range(n // 8):
+        acc = (acc + (xs[j] * xs[j]).astype(F)).astype(F)
+    ss = reduce_add8(acc)
+    ss = F(ss / F(n)); ss = F(ss + F(eps)); ss = F(F(1.0) / F(_libm.sqrtf(float(ss))))
+    t = (ss * x).astype(F)
+    return ((F(1.0) + w).astype(F) * t).astype(F) if add_unit else (w * t).astype(F)
+
+
+def round_half_away(v):
+    return np.where(v >= 0, np.floor(v + F(0.5)), np.ceil(v - F(0.5))).astype(F)
+
+
+def quantize_q8(x, gs=128):
+    g = x.reshape(-1, gs)
+    wmax = np.abs(g).max(axis=1).astype(F)
+    scale = (wmax / F(127.0)).astype(F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = (g / scale[:, None]).astype(F)
+    # f32::round is exact on the f32 value; v+0.5 in f32 could double-round, so do it in float64
+    r = np.where(q >= 0, np.floor(q.astype(np.float64) + 0.5), np.ceil(q.astype(np.float64) - 0.5))
+    r = np.nan_to_num(r, nan=0.0)
+    return np.clip(r, -128, 127).astype(np.int8).reshape(-1), scale
+
+
+def quantize_q4(x, gs=128):
+    g = x.reshape(-1, gs)
+    wmax = np.abs(g).max(axis=1).astype(F)
+    scale = (wmax / F(-8.0)).astype(F)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = ((g / scale[:, None]).astype(F) + F(8.0)).astype(F)
+    r = np.where(q >= 0, np.floor(q.astype(np.float64) + 0.5), np.ceil(q.astype(np.float64) - 0.5))
+    r = np.clip(np.nan_to_num(r, nan=0.0), 0, 15).astype(np.uint8)
+    r = r.reshape(-1, 2)
+    return (r[:, 0] | (r[:, 1] << 4)).astype(np.uint8), scale
+
+
+def unpack_q4(b):
+    b = b.astype(np.int32)
+    lo = (b & 0x0F) - 8
+    hi = ((b >> 4) & 0x0F) - 8
+    return np.stack([lo, hi], axis=-1).reshape(*b.shape[:-1], -1)
+
+
+def matmul_q(xq, xs, wq, ws, n, o, gs, q4):
+    """matmul_q8 / matmul_q4 (decode form): per row, groups ascending, ((ival as f32) * ws) * xs."""
+    if q4:
+        W = unpack_q4(wq.reshape(o, n // 2)); X = unpack_q4(xq.reshape(1, n // 2))[0]
+    else:
+        W = wq.reshape(o, n).astype(np.int32); X = xq.astype(np.int32)
+    G = n // gs
+    isum = (W.reshape(o, G, gs) * X.reshape(1, G, gs)).sum(axis=2).astype(np.int32)
+    WS = ws.reshape(o, G)
+    out = np.zeros(o, F)
+    for g in range(G):
+        p = (isum[:, g].astype(F) * WS[:, g]).astype(F)
+        p = (p * xs[g]).astype(F)
+        out = (out + p).astype(F)
+    if not q4:
+        out[(o // 4) * 4:] = 0
+    return out
+
+
+PHI_SHORT = [1.08, 1.1, 1.1300000000000001, 1.2800000000000002, 1.3100000000000003, 1.4500000000000004, 1.4500000000000004, 1.9500000000000008,
+             2.030000000000001, 2.4299999999999926, 2.5699999999999896, 2.9499999999999815, 3.729999999999965, 3.869999999999962, 4.189999999999955,
+             4.43999999999995, 4.6399999999999455, 4.979999999999938, 5.159999999999934, 5.279999999999932, 5.759999999999922, 5.889999999999919,
+             5.889999999999919, 5.969999999999917, 6.089999999999915, 6.2799999999999105, 6.7699999999999, 6.8899999999998975, 7.109999999999893,
+             7.129999999999892, 7.179999999999891, 7.289999999999889, 7.339999999999888, 7.559999999999883, 7.619999999999882, 7.69999999999988,
+             7.879999999999876, 7.879999999999876, 7.879999999999876, 7.939999999999875, 7.949999999999875, 7.979999999999874, 8.19999999999987,
+             8.439999999999864, 8.469999999999864, 8.589999999999861, 8.809999999999857, 8.999999999999853]
+
+
+class NumpyModel:
+    def __init__(self, image: np.ndarray):
+        d = image.tobytes()
+        assert d[:4] == b"lmrs"
+        (self.dim, self.hidden, self.L, self.n_heads, self.hs, self.n_kv, self.vocab, self.seq_len, self.eps, self.theta) = struct.unpack("IIIIIIIIff", d[8:48])
+        self.q_type, self.model_type = d[48], d[49]
+        self.gs = struct.unpack("I", d[50:54])[0]
+        self.seq_len = min(self.seq_len, 8192)
+        self.att = self.n_heads * self.hs; self.kv = self.n_kv * self.hs
+        off = [256]
+        img = image
+
+        def f32(cnt):
+            a = img[off[0]:off[0] + cnt * 4].view(F); off[0] += cnt * 4; return a
+
+        def quant(n_t, each):
+            out = []
+            for _ in range(n_t):
+                qb = each // 2 if self.q_type == 2 else each
+                q = img[off[0]:off[0] + qb]; off[0] += qb
+                s = img[off[0]:off[0] + each // self.gs * 4].view(F); off[0] += each // self.gs * 4
+                out.append((q.view(np.uint8) if self.q_type == 2 else q.view(np.int8), s))
+            return out
+        dim, L, att, kv, hid, V = self.dim, self.L, self.att, self.kv, self.hidden, self.vocab
+        gem = self.model_type == 0
+        self.emb = quant(1, V * dim)[0]
+        self.rms_att = f32(L * dim).reshape(L, dim)
+        self.wq = quant(L, dim * att); self.wk = quant(L, dim * kv); self.wv = quant(L, dim * kv); self.wo = quant(L, dim * att)
+        self.rms_post = f32(L * dim).reshape(L, dim)
+        if gem: self.rms_pre_ffn = f32(L * dim).reshape(L, dim)
+        self.w1 = quant(L, dim * hid); self.w2 = quant(L, dim * hid); self.w3 = quant(L, dim * hid)
+        if gem: self.rms_post_ffn = f32(L * dim).reshape(L, dim)
+        self.rms_final = f32(dim)
+        self.lm_head = quant(1, dim * V)[0] if self.model_type == 2 else self.emb
+        self.end = off[0]
+        self.kc = np.zeros((L, self.seq_len, kv), F); self.vc = np.zeros((L, self.seq_len, kv), F)
+
+    def _q(self, x):
+        return quantize_q4(x, self.gs) if self.q_type == 2 else quantize_q8(x, self.gs)
+
+    def _mm(self, xq, xs, w, n, o):
+        return matmul_q(xq, xs, w[0], w[1], n, o, self.gs, self.q_type == 2)
+
+    def embed(self, token):
+        q, s = self.emb
+        if self.q_type == 2:
+            vals = unpack_q4(q[token * self.dim // 2:(token + 1) * self.dim // 2].reshape(1, -1))[0].astype(F)
+        else:
+            vals = q[token * self.dim:(token + 1) * self.dim].astype(F)
+        idx = (token * self.dim + np.arange(self.dim)) // self.gs
+        return (vals * s[idx]).astype(F)
+
+    def rope(self, pos, j):
+        freq = F(F(1.0) / F(_libm.powf(float(F(self.theta)), float(F(F(2 * j) / F(self.hs))))))
+        sf = F(1.0)
+        if self.model_type == 1:
+            wavelen = F(F(F(2.0) * F(math.pi)) / freq)
+            factor, lo, hi, old = F(32.0), F(1.0), F(4.0), F(8192.0)
+            if wavelen > F(old / lo):
+                freq = F(freq / factor)
+            elif F(old / hi) <= wavelen <= F(old / lo):
+                sm = F(F(F(old / wavelen) - lo) / F(hi - lo))
+                freq = F(F(F(F(F(1.0) - sm) * freq) / factor) + F(sm * freq))
+        if self.model_type == 2:
+            freq = F(freq * F(1.0 / PHI_SHORT[j]))
+            sf = F(_libm.sqrtf(float(F(F(1.0) + F(F(_libm.logf(32.0)) / F(_libm.logf(4096.0)))))))
+        val = F(F(pos) * freq)
+        return F(F(_libm.cosf(float(val))) * sf), F(F(_libm.sinf(float(val))) * sf)
+
+    def layer(self, x, l, pos):
+        gem = self.model_type == 0
+        dim, hs, att, kv = self.dim, self.hs, self.att, self.kv
+        xn = rmsnorm(x, self.rms_att[l], self.eps, gem)
+        xq, xs = self._q(xn)
+        q = self._mm(xq, xs, self.wq[l], dim, att)
+        k = self._mm(xq, xs, self.wk[l], dim, kv)
+        v = self._mm(xq, xs, self.wv[l], dim, kv)
+        half = hs // 2
+        for i in range(self.n_heads):
+            for j in range(half):
+                c, s = self.rope(pos, j)
+                for vec, ok in ((q, True), (k, i * hs + j + half < kv)):
+                    if ok:
+                        v0, v1 = vec[i * hs + j], vec[i * hs + j + half]
+                        vec[i * hs + j] = F(F(v0 * c) - F(v1 * s))
+                        vec[i * hs + j + half] = F(F(v0 * s) + F(v1 * c))
+        self.kc[l, pos] = k; self.vc[l, pos] = v
+        out = np.zeros(att, F)
+        kvm = self.n_heads // self.n_kv
+        for h in range(self.n_heads):
+            qh = q[h * hs:(h + 1) * hs]
+            sc = np.zeros(pos + 1, F)
+            for t in range(pos + 1):
+                kk = self.kc[l, t, (h // kvm) * hs:(h // kvm + 1) * hs]
+                s_ = F(0.0)
+                for d_ in range(hs):
+                    s_ = F(s_ + F(qh[d_] * kk[d_]))
+                s_ = F(s_ / F(_libm.sqrtf(float(hs))))
+                if gem:
+                    s_ = F(s_ / F(50.0)); s_ = F(_libm.tanh(float(s_))); s_ = F(s_ * F(50.0))
+                    s_ = F(s_ + (F(0.0) if pos - t <= 4096 else F(-2.3819763e38)))
+                sc[t] = s_
+            mx = sc.max()
+            sm = F(0.0)
+            for t in range(pos + 1):
+                sc[t] = expf(F(sc[t] - mx)); sm = F(sm + sc[t])
+            sc = (sc / sm).astype(F)
+            o = np.zeros(hs, F)
+            for t in range(pos + 1):
+                o = (o + (sc[t] * self.vc[l, t, (h // kvm) * hs:(h // kvm + 1) * hs]).astype(F)).astype(F)
+            out[h * hs:(h + 1) * hs] = o
+        aq, as_ = self._q(out)
+        wo = self._mm(aq, as_, self.wo[l], att, dim)
+        if gem:
+            x = (x + rmsnorm(wo, self.rms_post[l], self.eps, True)).astype(F)
+            e = rmsnorm(x, self.rms_pre_ffn[l], self.eps, True)
+        else:
+            x = (x + wo).astype(F)
+            e = rmsnorm(x, self.rms_post[l], self.eps, False)
+        eq, es = self._q(e)
+        g = self._mm(eq, es, self.w1[l], dim, self.hidden)
+        u = self._mm(eq, es, self.w3[l], dim, self.hidden)
+        for i in range(self.hidden):
+            val = g[i]
+            if gem:
+                cube = F(F(F(F(0.044715) * val) * val) * val)
+                th = _libm.tanh(0.7978845608028654 * float(F(val + cube)))
+                val = F(val * F(F(0.5) * F(F(1.0) + F(th))))
+            else:
+                val = F(val * F(F(1.0) / F(F(1.0) + expf(F(-val)))))
+            g[i] = F(val * u[i])
+        hq, hs_ = self._q(g)
+        ff = self._mm(hq, hs_, self.w2[l], self.hidden, dim)
+        if gem:
+            return (x + rmsnorm(ff, self.rms_post_ffn[l], self.eps, True)).astype(F)
+        return (x + ff).astype(F)
+
+    def forward(self, token, pos):
+        x = self.embed(token)
+        if self.model_type == 0:
+            x = (x * F(_libm.sqrtf(float(self.dim)))).astype(F)
+        for l in range(self.L):
+            x = self.layer(x, l, pos)
+        x = rmsnorm(x, self.rms_final, self.eps, self.model_type == 0)
+        xq, xs = self._q(x)
+        logits = self._mm(xq, xs, self.lm_head, self.dim, self.vocab)
+        if self.model_type == 0:
+            for d_ in range(self.dim):
+                v = F(logits[d_] / F(30.0)); v = F(_libm.tanh(float(v))); logits[d_] = F(v * F(30.0))
+        return logits

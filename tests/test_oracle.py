@@ -1,0 +1,109 @@
+"""CPU-side checks of the oracle itself: committed golden vectors, edge cases the reference's code implies,
+and the equivalence the HIP fill_kv_cache relies on."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from tools import synth_lmrs as S
+
+GOLD = [("tiny_llama_q8", "tiny-llama", 7), ("tiny_llama_q4", "tiny-llama", 7), ("tiny_gemma_q8", "tiny-gemma", 8),
+        ("tiny_gemma_q4", "tiny-gemma", 8), ("tiny_phi_q8", "tiny-phi", 9), ("tiny_llama_f32", "tiny-llama", 7)]
+
+
+@pytest.mark.parametrize("name,cfg,seed", GOLD)
+def test_committed_golden_vectors(golden_dir, name, cfg, seed):
+    img = np.fromfile(os.path.join(golden_dir, name + ".lmrs"), np.uint8)
+    toks = np.load(os.path.join(golden_dir, name + ".tokens.npy"))
+    logits = np.load(os.path.join(golden_dir, name + ".logits.npy"))
+    prompt = S.prompt_tokens(cfg, 5, seed)
+    o = O.Oracle(img)
+    assert (o.generate_greedy(prompt, len(toks)) == toks).all()
+    o2 = O.Oracle(img)
+    lg = None
+    for pos, t in enumerate(list(prompt) + list(toks[:-1])):
+        lg = o2.forward(int(t), pos)
+    assert (lg.view(np.uint32) == logits.view(np.uint32)).all()
+
+
+def test_thread_count_never_changes_bits():
+    img = S.build_image("tiny-llama", S.Q8_0, 3)
+    prompt = S.prompt_tokens("tiny-llama", 4, 3)
+    outs = []
+    for n in (1, 2, 5):
+        O.set_threads(n)
+        o = O.Oracle(img)
+        outs.append([o.forward(int(t), p).copy() for p, t in enumerate(prompt)])
+    O.set_threads(4)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_quantize_edge_cases():
+    x = np.zeros(256, np.float32)
+    x[:128] = np.linspace(-1, 1, 128, dtype=np.float32)
+    q, s = O.quantize(x)
+    assert s[1] == 0 and (q[128:] == 0).all()                 # 0/0 = NaN -> `as i8` = 0 (quantization.rs:62-63)
+    assert q[:128].min() == -127 and q[:128].max() == 127
+    y = np.zeros(128, np.float32); y[0] = 127.0; y[1] = 63.5; y[2] = -63.5; y[3] = 0.49999997
+    q, s = O.quantize(y)
+    assert s[0] == 1.0 and list(q[:4]) == [127, 64, -64, 0]   # f32::round: half away from zero
+    q4, s4 = O.quantize_q4(y)
+    assert s4[0] == np.float32(127.0 / -8.0)
+    assert q4[0] & 0x0F == 0 and (q4[0] >> 4) == 4            # 127/(-15.875)+8 = 0 ; 63.5/(-15.875)+8 = 4
+
+
+def test_argmax_first_maximum_wins():
+    p = np.array([1, 5, 5, 2], np.float32)
+    assert O.lib().lmrs_ref_argmax(p.ctypes.data, 4) == 1
+    p = np.array([np.nan, 9, 1], np.float32)
+    assert O.lib().lmrs_ref_argmax(p.ctypes.data, 3) == 0     # NaN at index 0 is never displaced (strict >)
+    p = np.array([-np.inf, -np.inf], np.float32)
+    assert O.lib().lmrs_ref_argmax(p.ctypes.data, 2) == 0
+
+
+def test_softmax_single_and_masked():
+    assert O.softmax(np.array([3.0], np.float32))[0] == 1.0
+    s = O.softmax(np.array([0.0, -2.3819763e38], np.float32))
+    assert s[0] == 1.0 and s[1] == 0.0
+
+
+@pytest.mark.parametrize("cfg,q", [("tiny-llama", S.Q8_0), ("tiny-phi", S.Q8_0)])
+def test_fill_kv_cache_layer_major_equals_token_major(cfg, q):
+    """forward_layer(sl=n) over all layers (transformer.rs:672-684) == n single-token passes: the identity the
+    HIP fill_kv_cache is built on."""
+    img = S.build_image(cfg, q, 21)
+    toks = S.prompt_tokens(cfg, 7, 21)
+    a = O.Oracle(img); b = O.Oracle(img)
+    e = a.get_embeddings(toks)
+    batched = e.copy()
+    assert a.fill_kv_cache(batched, 2) == 9
+    dim = a.args.dim
+    one_by_one = e.copy()
+    for i in range(len(toks)):
+        row = one_by_one[i * dim:(i + 1) * dim].copy()
+        b.fill_kv_cache(row, 2 + i)
+        one_by_one[i * dim:(i + 1) * dim] = row
+    assert (batched.view(np.uint32) == one_by_one.view(np.uint32)).all()
+    for l in range(a.args.n_layers):
+        for p in range(2, 9):
+            for w in (0, 1):
+                assert (a.kv_row(w, l, p).view(np.uint32) == b.kv_row(w, l, p).view(np.uint32)).all()
+    la = a.forward(3, 9).copy(); lb = b.forward(3, 9).copy()
+    assert (la.view(np.uint32) == lb.view(np.uint32)).all()
+
+
+def test_generate_matches_manual_loop():
+    img = S.build_image("tiny-llama", S.Q8_0, 5)
+    prompt = S.prompt_tokens("tiny-llama", 4, 5)
+    a = O.Oracle(img); b = O.Oracle(img)
+    toks = a.generate_greedy(prompt, 6)
+    nxt, out = None, []
+    for s in range(4 + 5):
+        t = int(prompt[s]) if s < 4 else nxt
+        nxt = b.forward_argmax(t, s)
+        if s >= 3:
+            out.append(nxt)
+    assert out == list(map(int, toks))

@@ -1,0 +1,42 @@
+"""The C oracle against an independent numpy transcription of the same Rust sources (tests/numpy_ref.py),
+on the golden fixtures the reference's export.py produced.  Bit-exact logits at every step."""
+import os
+
+import numpy as np
+import pytest
+
+import numpy_ref as NR
+import oracle_lib as O
+from tools import synth_lmrs as S
+
+CASES = [("tiny_llama_q8", "tiny-llama", 7), ("tiny_llama_q4", "tiny-llama", 7), ("tiny_gemma_q8", "tiny-gemma", 8),
+         ("tiny_gemma_q4", "tiny-gemma", 8), ("tiny_phi_q8", "tiny-phi", 9)]
+
+
+@pytest.mark.parametrize("name,cfg,seed", CASES)
+def test_oracle_matches_numpy_transcription(golden_dir, name, cfg, seed):
+    img = np.fromfile(os.path.join(golden_dir, name + ".lmrs"), np.uint8)
+    orc = O.Oracle(img)
+    ref = NR.NumpyModel(img)
+    assert ref.end == orc.bytes_consumed == img.size
+    prompt = S.prompt_tokens(cfg, 3, seed)
+    tok = None
+    for pos in range(5):
+        t = int(prompt[pos]) if pos < len(prompt) else tok
+        lo = orc.forward(t, pos).copy()
+        ln = ref.forward(t, pos)
+        assert (lo.view(np.uint32) == ln.view(np.uint32)).all(), f"{name} pos {pos}: {np.flatnonzero(lo != ln)[:5]}"
+        tok = int(np.argmax(lo))
+
+
+def test_ops_match_numpy():
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(512) * 3).astype(np.float32)
+    q, s = O.quantize(x); qn, sn = NR.quantize_q8(x)
+    assert (q == qn).all() and (s.view(np.uint32) == sn.view(np.uint32)).all()
+    q4, s4 = O.quantize_q4(x); q4n, s4n = NR.quantize_q4(x)
+    assert (q4 == q4n).all() and (s4.view(np.uint32) == s4n.view(np.uint32)).all()
+    w = (1 + 0.1 * rng.standard_normal(512)).astype(np.float32)
+    for unit in (False, True):
+        a = O.rmsnorm(x, w, 1e-5, unit); b = NR.rmsnorm(x, w, 1e-5, unit)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()

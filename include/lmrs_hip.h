@@ -126,6 +126,10 @@ int lmrs_op_expf(int device, float* y, const float* x, size_t n);
  * us5[k] = summed duration (microseconds), bytes5[k] = summed algorithmic bytes (int8 + f32 scales),
  * count5[k] = launches.  Activations hold garbage afterwards; weights and older KV rows are untouched. */
 int lmrs_bench_gemv(lmrs_ctx* ctx, int iters, double* us5, double* bytes5, int* count5);
+/* Debug timeline (LMRS_DEBUG_TIMELINE=1 in the environment at lmrs_create): 8 wall-clock stamps (100 MHz) per
+ * kernel of the last decode step, in launch order: [0..3] first workgroup, [4..7] last workgroup:
+ * start, prologue done, first rows done, end. */
+int lmrs_debug_timeline(lmrs_ctx* ctx, unsigned long long* out, int max_nodes, int* n_nodes);
 /* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos`. */
 int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);
 

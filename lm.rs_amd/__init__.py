@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline",
 ]
 
 
@@ -79,6 +79,7 @@ def lib():
         L.lmrs_op_expf.argtypes = [C.c_int, vp, vp, sz]
         L.lmrs_bench_gemv.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.lmrs_step_info.argtypes = [vp, u32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.lmrs_debug_timeline.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -161,6 +162,12 @@ class Transformer:
         _chk(lib().lmrs_bench_gemv(self._h, iters, us, b, n))
         names = ["qkv", "wo", "w1w3", "w2", "classifier"]
         return {names[k]: (us[k], b[k], n[k]) for k in range(5)}
+
+    def debug_timeline(self):
+        """-> uint64[n_kernels, 8] wall-clock stamps (10 ns units) of the last decode step (needs LMRS_DEBUG_TIMELINE=1)."""
+        buf = np.zeros((1024, 8), np.uint64); n = C.c_int()
+        _chk(lib().lmrs_debug_timeline(self._h, _p(buf), 1024, C.byref(n)))
+        return buf[: n.value]
 
     def step_info(self, pos: int):
         n, b = C.c_int(), C.c_double()

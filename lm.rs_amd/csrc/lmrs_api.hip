@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -63,6 +64,7 @@ struct lmrs_ctx {
     float *k_cache = nullptr, *v_cache = nullptr, *rope = nullptr;
     float* stage = nullptr; size_t stage_floats = 0;        // device staging for fill_kv_cache / get_embeddings
     uint32_t* tokens = nullptr; DevState* st = nullptr;
+    unsigned long long* dbg = nullptr; int dbg_node = 0;     // LMRS_DEBUG_TIMELINE=1: 8 stamps per kernel node
     // pinned host
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
@@ -129,21 +131,26 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
     g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
     g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
+    g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_QKV, c->stream));
     // 2. RoPE + attention                                               (:443-544)
     AttnArgs t{};
     t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->att_out;
     t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.seq_len = a.seq_len; t.layer = l;
     t.gemma = gemma; t.st = c->st;
+    t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_attention(t, c->stream));
     // 3. quantize | Wo | x += ...                                       (:550-576)
     g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = c->x;
+    g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_QUANT, EPI_RESID, c->stream));
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
     g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h;
+    g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_SWIGLU, c->stream));
     // 5. quantize | W2 | x += ...                                       (:630-654)
     g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = c->x;
+    g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_QUANT, EPI_RESID, c->stream));
     return 0;
 }
@@ -171,16 +178,20 @@ EmbedArgs embed_args(lmrs_ctx* c) {
 int enqueue_step(lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     for (uint32_t l = 0; l < a.n_layers; ++l) if (enqueue_layer(c, (int)l)) return -1;
+    c->dbg_node = c->dbg_node;   // (nodes numbered in launch order)
     GemvArgs g = cls_args(c);                                   // final rmsnorm + quantize | classifier | argmax partials (:341-381)
+    g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
     ArgmaxArgs m{};
     m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c);
+    m.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
 }
 
 int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out) {
     hipGraph_t graph = nullptr;
+    c->dbg_node = 0;
     HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
     if (full) rc = enqueue_step(c);
@@ -237,7 +248,7 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     const size_t dim = a.dim, att = (size_t)a.n_heads * a.head_size, kv = (size_t)a.n_kv_heads * a.head_size, hid = a.hidden_dim, V = a.vocab_size;
     if (dim % 128 || att % 128 || hid % 128) return fail("dim, n_heads*head_size and hidden_dim must be multiples of 128");
     if (dim > 10240 || att > 10240 || hid > 10240) return fail("vector length above 10240 not supported");
-    if (a.head_size % 4 || (a.head_size & 1)) return fail("head_size must be a multiple of 4");
+    if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128 && a.head_size != 256) return fail("head_size must be 64, 96, 128 or 256 (the model families lm.rs supports)");
     int ndev = 0;
     hipError_t de = hipGetDeviceCount(&ndev);
     if (de != hipSuccess || ndev == 0) return fail("no HIP device available (this library has no CPU fallback)");
@@ -274,7 +285,7 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     need(dim * 4); need(att * 4); need(kv * 4); need(att * 4); need(hid * 4); need(V * 4);
     need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
-    c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4);
+    c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8);
     total += 4096;
     HCK(hipMalloc(reinterpret_cast<void**>(&c->arena), total));
     c->arena_bytes = total;
@@ -336,6 +347,7 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V);
     c->part_val = c->alloc<float>(kMaxArgmaxParts); c->part_idx = c->alloc<int>(kMaxArgmaxParts);
     c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
+    if (getenv("LMRS_DEBUG_TIMELINE")) { c->dbg = c->alloc<unsigned long long>(8 * 1024); if (c->dbg) HCK(hipMemsetAsync(c->dbg, 0, 8 * 1024 * 8, c->stream)); }
     c->stage = c->alloc<float>(c->stage_floats);
     if (!c->stage) { fail("arena overflow"); return cleanup(); }
     HCK(hipMemsetAsync(c->k_cache, 0, kvn * 4, c->stream)); HCK(hipMemsetAsync(c->v_cache, 0, kvn * 4, c->stream));   // :302-303
@@ -356,7 +368,7 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     HCK(hipStreamSynchronize(c->stream));
     {
         GemvArgs g = cls_args(c);
-        c->cls_grid = gemv_grid(g, EPI_CLS);
+        c->cls_grid = gemv_grid(g, PRO_RMS_QUANT, EPI_CLS);
     }
     CK(capture(c, true, &c->g_step));
     CK(capture(c, false, &c->g_layers));
@@ -522,6 +534,19 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
             }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+// Debug timeline (LMRS_DEBUG_TIMELINE=1 at lmrs_create): 8 stamps (100 MHz wall clock) per kernel node of the
+// last replay of the step graph: [0..3] first workgroup, [4..7] last workgroup: start, prologue done, first pass, end.
+extern "C" int lmrs_debug_timeline(lmrs_ctx* c, unsigned long long* out, int max_nodes, int* n_nodes) {
+    if (!c || !c->dbg) return fail("debug timeline not enabled (set LMRS_DEBUG_TIMELINE=1 before lmrs_create)");
+    HIP_OK(hipSetDevice(c->device));
+    const int n = 5 * (int)c->args.n_layers + 2;
+    const int m = n < max_nodes ? n : max_nodes;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipMemcpy(out, c->dbg, (size_t)m * 8 * 8, hipMemcpyDeviceToHost));
+    if (n_nodes) *n_nodes = m;
     return 0;
 }
 

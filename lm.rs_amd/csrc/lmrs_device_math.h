@@ -31,6 +31,13 @@ __device__ __forceinline__ float group32_max(float v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() also waits for every
+// outstanding global load (s_waitcnt vmcnt(0)), which would drain the weight stream that is deliberately
+// left in flight across the activation prologue; the kernels below only ever hand LDS data across a
+// barrier, so lgkmcnt(0) + s_barrier is sufficient (global results are consumed by the lane that loaded
+// them, under the compiler's own counted vmcnt waits).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------- f32::exp == glibc expf
 // Restatement of glibc >= 2.27 expf (sysdeps/ieee754/flt-32/e_expf.c; N = 32 table + cubic in double)
 // as compiled for x86-64 CPUs with FMA (the ifunc'd __expf_fma build, where GCC fuses every a*b+c).
@@ -46,23 +53,37 @@ __device__ const uint64_t EXP2F_TAB[32] = {
     0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-__device__ __forceinline__ float expf_glibc(float x) {
+// The 32-entry table costs a dependent global load per call; hot kernels instead keep entry (lane & 31) in a
+// register pair per lane (exp2f_tab_lane(), loaded once at kernel start under the other loads) and fetch
+// T[ki % 32] with two ds_bpermute lane reads (expf_glibc_t).  Same arithmetic, same bits.
+__device__ __forceinline__ uint64_t exp2f_tab_lane() { return EXP2F_TAB[threadIdx.x & 31]; }
+
+template <bool LANE_TAB>
+__device__ __forceinline__ float expf_glibc_impl(float x, uint64_t lane_tab) {
     const double InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
     const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
     const uint32_t ux = __float_as_uint(x);
     const uint32_t abstop = (ux >> 20) & 0x7ff;
-    if (abstop >= 0x42b) {                                   // |x| >= 88 or NaN
-        if (ux == 0xff800000u) return 0.0f;
-        if (abstop >= 0x7f8) return x + x;
-        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);
-        if (x < -0x1.9fe368p6f) return 0.0f;
+    // special cases (|x| >= 88 or NaN) are resolved by selection AFTER the main path so that every lane stays
+    // active through the lane-table shuffles
+    bool special = false; float sval = 0.0f;
+    if (abstop >= 0x42b) {
+        if (ux == 0xff800000u) { special = true; sval = 0.0f; }
+        else if (abstop >= 0x7f8) { special = true; sval = x + x; }
+        else if (x > 0x1.62e42ep6f) { special = true; sval = __uint_as_float(0x7f800000u); }
+        else if (x < -0x1.9fe368p6f) { special = true; sval = 0.0f; }
     }
-    const double xd = (double)x;
+    const double xd = special ? 0.0 : (double)x;
     double kd = __builtin_fma(InvLn2N, xd, SHIFT);
     const uint64_t ki = (uint64_t)__double_as_longlong(kd);
     kd = kd - SHIFT;
     const double r = __builtin_fma(InvLn2N, xd, -kd);
-    uint64_t t = EXP2F_TAB[ki % 32];
+    uint64_t t;
+    if constexpr (LANE_TAB) {
+        const int src = (int)((threadIdx.x & 32) | (unsigned)(ki & 31));          // same half-wave, lane ki % 32
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)lane_tab, src), hi = (unsigned)__shfl((int)(unsigned)(lane_tab >> 32), src);
+        t = ((uint64_t)hi << 32) | lo;
+    } else t = EXP2F_TAB[ki % 32];
     t += ki << (52 - 5);
     const double s = __longlong_as_double((long long)t);
     const double z = __builtin_fma(C0, r, C1);
@@ -70,8 +91,11 @@ __device__ __forceinline__ float expf_glibc(float x) {
     double y = __builtin_fma(C2, r, 1.0);
     y = __builtin_fma(z, r2, y);
     y = y * s;
-    return (float)y;
+    return special ? sval : (float)y;
 }
+__device__ __forceinline__ float expf_glibc(float x) { return expf_glibc_impl<false>(x, 0); }
+// All lanes of the wave must call this together (it shuffles).
+__device__ __forceinline__ float expf_glibc_t(float x, uint64_t lane_tab) { return expf_glibc_impl<true>(x, lane_tab); }
 
 // ---------------------------------------------------------------- quantize primitives (quantization.rs:44-95)
 // Rust `f32 as i8` after f32::round: saturating, NaN -> 0.

@@ -33,6 +33,7 @@ struct GemvArgs {
     const DevState* st;
     // EPI_CLS
     float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on rows < softcap_rows
+    unsigned long long* dbg; // optional: 8 wall-clock stamps (debug timeline)
 };
 
 struct AttnArgs {
@@ -43,6 +44,7 @@ struct AttnArgs {
     float* out;              // att_dim
     int n_heads, n_kv_heads, head_size, seq_len, layer, gemma;
     int chunk;               // timesteps staged through LDS at a time (set by launch_attention)
+    unsigned long long* dbg; // optional: 8 wall-clock stamps (debug timeline)
     const DevState* st;
 };
 
@@ -58,11 +60,12 @@ struct ArgmaxArgs {
     const float* logits;
     uint32_t* tokens; DevState* st;
     EmbedArgs emb;           // the winner's (or the next prompt token's) embedding row is written to emb.x
+    unsigned long long* dbg;
 };
 
 // launches (all asynchronous on `s`)
 hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint = 0);
-int gemv_grid(const GemvArgs& a, int epi);               // number of workgroups launch_gemv uses
+int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s);

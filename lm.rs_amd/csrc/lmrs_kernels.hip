@@ -29,6 +29,7 @@
 //     saves a dependent kernel boundary (~1.2-1.9 us on this chip) per use.
 #include "lmrs_device_math.h"
 #include "lmrs_kernels.h"
+#include "lmrs_stage.h"
 
 namespace lmrs {
 
@@ -67,28 +68,28 @@ __device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[NP], const float4 (&
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (t < 64) {
         // lanes 0..7: the 8 strided partial sums, each a sequential chain over j (ss_sim += x*x).
         // The adds are inherently serial (float addition is not associative); the LDS reads are not, so
-        // they are issued 8 x 16 B ahead of the chain (two register batches, ping-pong).
+        // they are issued 4 x 16 B ahead of the chain (two register batches, ping-pong).
         float p = 0.0f;
         if (t < 8) {
             const float4* row = reinterpret_cast<const float4*>(scratch + t * JP);
             const int nj4 = n >> 5;                          // (n/8)/4 float4 per row  (n % 32 == 0)
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);   // p >= +0, so p + 0 == p exactly: padding is free
-            float4 A[8], B[8];
+            float4 A[4], B[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) A[u] = u < nj4 ? row[u] : z4;
-            for (int j0 = 0; j0 < nj4; j0 += 16) {
+            for (int u = 0; u < 4; ++u) A[u] = u < nj4 ? row[u] : z4;
+            for (int j0 = 0; j0 < nj4; j0 += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) B[u] = (j0 + 8 + u) < nj4 ? row[j0 + 8 + u] : z4;
+                for (int u = 0; u < 4; ++u) B[u] = (j0 + 4 + u) < nj4 ? row[j0 + 4 + u] : z4;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
+                for (int u = 0; u < 4; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) A[u] = (j0 + 16 + u) < nj4 ? row[j0 + 16 + u] : z4;
+                for (int u = 0; u < 4; ++u) A[u] = (j0 + 8 + u) < nj4 ? row[j0 + 8 + u] : z4;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
+                for (int u = 0; u < 4; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
             }
         }
         const float p0 = __shfl(p, 0), p1 = __shfl(p, 1), p2 = __shfl(p, 2), p3 = __shfl(p, 3);
@@ -101,7 +102,7 @@ __device__ __forceinline__ void rmsnorm_inplace(float4 (&v)[NP], const float4 (&
             scratch[8 * JP] = ss;
         }
     }
-    __syncthreads();
+    lds_barrier();
     const float ss = scratch[8 * JP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -190,7 +191,6 @@ __device__ __forceinline__ void load_vec(float4 (&v)[NP], const float* __restric
 // ------------------------------------------------------------------------------------------------
 // Fused dequant-GEMV
 // ------------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));     // native vector: what the nontemporal builtin accepts
 __device__ __forceinline__ i32x4 ld_nt(const i32x4* p) { return __builtin_nontemporal_load(p); }
 
 // signed-nibble unpack of 4 packed bytes: per byte (v & 0xF) - 8 without cross-byte borrows
@@ -221,13 +221,31 @@ __device__ __forceinline__ int group_partial_dot(const i32x4& w, const int8_t* x
     return d;
 }
 
+// Debug timeline: when a.dbg is set, lane 0 of the first and of the last workgroup record the 100 MHz
+// wall clock at four points (start, prologue done, first pass consumed, end).
+#define LMRS_STAMP(k)                                                                                         \
+    do {                                                                                                      \
+        if (a.dbg && threadIdx.x == 0) {                                                                      \
+            if (blockIdx.x == 0) a.dbg[k] = wall_clock64();                                                   \
+            if (blockIdx.x == gridDim.x - 1) a.dbg[4 + (k)] = wall_clock64();                                 \
+        }                                                                                                     \
+    } while (0)
+
 // L lanes per row, U steps in flight, PRO/EPI fused stages, Q4 = packed-nibble weights.
 // CL = lanes covering one quantisation group: 8 (Q8_0: 8 x 16 B = 128 B) or 4 (Q4_0: 4 x 16 B = 64 B).
+// A row is split into NC = L / CL contiguous segments, one per cluster of CL lanes; a cluster walks the
+// groups of its segment in ascending order, 16 B per lane per step (a full 128-B / 64-B line per cluster).
+//   NC == 1: the row's float accumulation `acc += (isum * ws) * xs` runs lane-locally, groups ascending.
+//   NC  > 1: every cluster first turns its (<= U) groups into products p, then the accumulation chain is
+//            run segment by segment — cluster j starts from cluster j-1's running sum (one cross-lane move
+//            per segment) — which is the reference's left-to-right order with NC-1 hops instead of G.
 template <int L, int U, int NP, int PRO, int EPI, bool Q4>
 __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CL = Q4 ? 4 : 8;
+    constexpr int NC = L / CL;
     static_assert(L >= CL && (L & (L - 1)) == 0 && L <= 64, "bad L");
+    LMRS_STAMP(0);
     const int n = a.n, G = n / kGS;
     int8_t* xq = reinterpret_cast<int8_t*>(smem);                       // n bytes
     float* xs = reinterpret_cast<float*>(smem + ((n + 15) & ~15));      // G floats
@@ -235,10 +253,12 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane % L;                       // lane within the row
+    const int cl = r / CL, rc = r % CL;           // cluster within the row, lane within the cluster
     constexpr int RW = 64 / L;                    // rows per wave
     constexpr int RB = RW * (kBlock / 64);        // rows per workgroup pass
     const int row_bytes = Q4 ? n / 2 : n;
-    const int steps = row_bytes / (16 * L);
+    const int Gc = G / NC;                        // groups (= steps) per cluster; host guarantees G % NC == 0 (and Gc <= U if NC > 1)
+    const int g0 = cl * Gc;                       // first group of my segment
     const int o = a.o;
     const int n_pass = (o + RB - 1) / RB;
 
@@ -251,16 +271,16 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         if constexpr (PRO == PRO_RMS_QUANT) load_vec(nw, a.rms_w, n);
     }
     i32x4 w[U]; float sc[U];
-    auto issue = [&](int pass, int k0) __attribute__((always_inline)) {
+    auto issue = [&](int pass, int s0) __attribute__((always_inline)) {
         int row = pass * RB + wave * RW + lane / L;
         row = row < o ? row : o - 1;
-        const i32x4* wrow = reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(a.wq) + (size_t)row * row_bytes) + r;
-        const float* srow = a.ws + (size_t)row * G;
+        const i32x4* wrow = reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(a.wq) + (size_t)row * row_bytes) + g0 * CL + rc;
+        const float* srow = a.ws + (size_t)row * G + g0;
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (k0 + u < steps) {
-                w[u] = ld_nt(wrow + (k0 + u) * L);
-                sc[u] = srow[((k0 + u) * L + r) / CL];
+            if (s0 + u < Gc) {
+                w[u] = ld_nt(wrow + (s0 + u) * CL);
+                sc[u] = srow[s0 + u];
             }
     };
     if ((int)blockIdx.x < n_pass) issue(blockIdx.x, 0);
@@ -283,42 +303,68 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         if constexpr (PRO == PRO_RMS_QUANT) rmsnorm_inplace(v, nw, n, a.eps, a.add_unit, scratch);
         quantize_to_lds<Q4, NP>(v, n, xq, xs, nullptr, nullptr);
     }
-    __syncthreads();
+    lds_barrier();
+    LMRS_STAMP(1);
 
     // ---------------- main loop
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;   // EPI_CLS
     bool preloaded = true;
+    const int wlane = NC == 1 ? 0 : L - CL;       // lane (within the row) that owns the finished sum
 
     for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
         const int row = pass * RB + wave * RW + lane / L;
         const bool valid = row < o;
         float acc = 0.0f;
-        for (int k0 = 0; k0 < steps; k0 += U) {
-            if (!preloaded) issue(pass, k0);
-            preloaded = false;
+        if constexpr (NC == 1) {
+            for (int s0 = 0; s0 < Gc; s0 += U) {
+                if (!preloaded) issue(pass, s0);
+                preloaded = false;
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (k0 + u < steps) {
-                    const int chunk = (k0 + u) * L + r;              // 16-byte chunk index within the row
-                    int d = group_partial_dot<Q4>(w[u], xq, chunk);
+                for (int u = 0; u < U; ++u)
+                    if (s0 + u < Gc) {
+                        const int g = s0 + u;
+                        int d = group_partial_dot<Q4>(w[u], xq, g * CL + rc);
+                        if constexpr (Q4) { d += dpp_i<0xB1>(d); d += dpp_i<0x4E>(d); }
+                        else d = cluster8_sum(d);
+                        float p = (float)d * sc[u];                  // (ival as f32) * w.s[..]
+                        p = p * xs[g];                               //   * x.s[..]
+                        acc = acc + p;                               // xout += ..., groups ascending
+                    }
+            }
+        } else {
+            if (!preloaded) issue(pass, 0);
+            preloaded = false;
+            float pb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pb[u] = 0.0f;
+                if (u < Gc) {
+                    const int g = g0 + u;
+                    int d = group_partial_dot<Q4>(w[u], xq, g * CL + rc);
                     if constexpr (Q4) { d += dpp_i<0xB1>(d); d += dpp_i<0x4E>(d); }
                     else d = cluster8_sum(d);
-                    float p = (float)d * sc[u];                      // (ival as f32) * w.s[..]
-                    p = p * xs[chunk / CL];                          //   * x.s[..]
-                    if constexpr (L == CL) acc = acc + p;            // xout += ..., groups ascending
-                    else {
-#pragma unroll
-                        for (int j = 0; j < L / CL; ++j) acc = acc + __shfl(p, (lane & ~(L - 1)) + j * CL);
-                    }
+                    float p = (float)d * sc[u];
+                    pb[u] = p * xs[g];
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const float carry = j == 0 ? 0.0f : __shfl(acc, (lane & ~(L - 1)) + (j - 1) * CL);
+                if (cl == j) {
+                    acc = carry;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) if (u < Gc) acc = acc + pb[u];
+                }
+            }
         }
-        // ---------------- epilogue (acc is replicated over the row's L lanes)
+        if (pass == (int)blockIdx.x) LMRS_STAMP(2);
+        // ---------------- epilogue (the finished sum is replicated over the lanes of the row's last cluster)
         if constexpr (EPI == EPI_STORE) {
-            if (valid && r == 0) a.out[row] = acc;
+            if (valid && r == wlane) a.out[row] = acc;
         } else if constexpr (EPI == EPI_RESID) {
-            if (valid && r == 0) a.out[row] = a.out[row] + acc;
+            if (valid && r == wlane) a.out[row] = a.out[row] + acc;
         } else if constexpr (EPI == EPI_QKV) {
-            if (valid && r == 0) {
+            if (valid && r == wlane) {
                 if (row < a.att_dim) a.out[row] = acc;
                 else if (row < a.att_dim + a.kv_dim) a.k_raw[row - a.att_dim] = acc;
                 else a.v_cache[((size_t)a.layer * a.seq_len + a.st->pos) * a.kv_dim + (row - a.att_dim - a.kv_dim)] = acc;
@@ -326,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         } else if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GELU) {
             // rows are interleaved: 2i = gate (w1) row i, 2i+1 = up (w3) row i
             const float up = __shfl_down(acc, L);
-            if (valid && r == 0 && ((lane / L) & 1) == 0) {
+            if (valid && r == wlane && ((lane / L) & 1) == 0) {
                 float val = acc;
                 if constexpr (EPI == EPI_SWIGLU) {
                     const float e = expf_glibc(-val);
@@ -343,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 a.out[row >> 1] = val;
             }
         } else if constexpr (EPI == EPI_CLS) {
-            if (valid && r == 0) {
+            if (valid && r == wlane) {
                 float vv = acc;
                 if (row < a.softcap_rows) {                   // transformer.rs:375-381 (first `dim` logits only)
                     vv = vv / 30.0f;
@@ -356,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         }
     }
 
+    LMRS_STAMP(3);
     if constexpr (EPI == EPI_CLS) {
         // workgroup argmax partial: larger value wins, ties -> lower index (== first index of the max)
 #pragma unroll
@@ -375,6 +422,135 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Static-shape fused dequant-GEMV (Q8_0): N, L compile-time (lmrs_stage.h).  One tile (U = groups per
+// cluster) covers a lane's whole share of a row; pass p handles rows p*RB .. p*RB+RB-1.
+// Issue order: activation (+ norm weight) loads, then the first tile; the prologue runs under the tile's
+// HBM latency with counted vmcnt waits; further passes are double-buffered (tile p+1 in flight while p is
+// consumed).
+// ------------------------------------------------------------------------------------------------
+template <int N, int L, int PRO, int EPI>
+__global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using R = RowGeom<N, L>;
+    using V = VecGeom<N>;
+    LMRS_STAMP(0);
+    int8_t* xq = reinterpret_cast<int8_t*>(smem);
+    float* xs = reinterpret_cast<float*>(smem + N);
+    float* scratch = xs + ((V::G + 3) & ~3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane % L;
+    const int o = a.o, n_pass = (o + R::RB - 1) / R::RB;
+    const int8_t* wq = reinterpret_cast<const int8_t*>(a.wq);
+
+    float4 v[V::NP], nw[V::NP];
+    if constexpr (PRO != PRO_PREQ) {
+        vec_load<N, false>(v, a.xin);
+        if constexpr (PRO == PRO_RMS_QUANT) vec_load<N, false>(nw, a.rms_w);
+    }
+    auto row_of = [&](int pass) __attribute__((always_inline)) { const int rw = pass * R::RB + wave * R::RW + lane / L; return rw < o ? rw : o - 1; };
+    uint64_t etab = 0;
+    if constexpr (EPI == EPI_SWIGLU) etab = exp2f_tab_lane();
+    asm volatile("" ::: "memory");               // keep the activation loads ahead of the weight tile in issue order
+    WTile<R::U> ta, tb;
+    int pass = blockIdx.x;                      // grid <= n_pass
+    tile_issue<N, L>(ta, wq, a.ws, row_of(pass));
+
+    if constexpr (PRO == PRO_PREQ) {
+        for (int e = threadIdx.x * 16; e < N; e += kBlock * 16)
+            *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
+        for (int g = threadIdx.x; g < V::G; g += kBlock) xs[g] = a.xs_in[g];
+    } else {
+        if constexpr (PRO == PRO_RMS_QUANT) vec_rmsnorm<N>(v, nw, a.eps, a.add_unit, scratch);
+        vec_quantize_q8<N>(v, xq, xs);
+    }
+    lds_barrier();
+    LMRS_STAMP(1);
+
+    float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;   // EPI_CLS
+    const bool writer = r >= L - 8 && (r & 7) == 0;                        // one lane of the row's last cluster
+
+    auto finish = [&](float acc, int ps) __attribute__((always_inline)) {
+        const int row = ps * R::RB + wave * R::RW + lane / L;
+        const bool valid = row < o;
+        if constexpr (EPI == EPI_STORE) {
+            if (valid && writer) a.out[row] = acc;
+        } else if constexpr (EPI == EPI_RESID) {
+            if (valid && writer) a.out[row] = a.out[row] + acc;
+        } else if constexpr (EPI == EPI_QKV) {
+            if (valid && writer) {
+                if (row < a.att_dim) a.out[row] = acc;
+                else if (row < a.att_dim + a.kv_dim) a.k_raw[row - a.att_dim] = acc;
+                else a.v_cache[((size_t)a.layer * a.seq_len + a.st->pos) * a.kv_dim + (row - a.att_dim - a.kv_dim)] = acc;
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            const float up = __shfl_down(acc, L);                       // rows interleaved: 2i gate, 2i+1 up
+            const float hval = swiglu_t(acc, up, etab);                 // all lanes (expf shuffles its table)
+            if (valid && writer && ((lane / L) & 1) == 0) a.out[row >> 1] = hval;
+        } else if constexpr (EPI == EPI_CLS) {
+            if (valid && writer) {
+                a.out[row] = acc;
+                if (acc > best) { best = acc; best_i = row; }
+            }
+        }
+    };
+
+    // double-buffered passes
+    for (;;) {
+        const int p1 = pass + gridDim.x;
+        if (p1 < n_pass) tile_issue<N, L>(tb, wq, a.ws, row_of(p1));
+        finish(tile_consume<N, L>(ta, xq, xs), pass);
+        if (pass == (int)blockIdx.x) LMRS_STAMP(2);
+        if (p1 >= n_pass) break;
+        const int p2 = p1 + gridDim.x;
+        if (p2 < n_pass) tile_issue<N, L>(ta, wq, a.ws, row_of(p2));
+        finish(tile_consume<N, L>(tb, xq, xs), p1);
+        if (p2 >= n_pass) break;
+        pass = p2;
+    }
+    LMRS_STAMP(3);
+    if constexpr (EPI == EPI_CLS) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(best_i, off);
+            if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+        }
+        __syncthreads();
+        float* rv = reinterpret_cast<float*>(smem); int* ri = reinterpret_cast<int*>(smem + 16);
+        if (lane == 0) { rv[wave] = best; ri[wave] = best_i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w2 = 1; w2 < kBlock / 64; ++w2)
+                if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
+            a.part_val[blockIdx.x] = best; a.part_idx[blockIdx.x] = best_i;
+        }
+    }
+}
+
+// Static classes: (N, L, PRO, EPI).  Q8_0, Llama/Phi glue.  Chosen when (n, pro, epi) matches and o suits L.
+#define LMRS_STATIC_TABLE(X)                                                                      \
+    /* dim 2048: Llama-3.2-1B */                                                                  \
+    X(2048, 32, PRO_RMS_QUANT, EPI_QKV) X(2048, 32, PRO_QUANT, EPI_RESID) X(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU) \
+    X(2048, 8, PRO_RMS_QUANT, EPI_CLS) X(2048, 32, PRO_PREQ, EPI_STORE) X(2048, 8, PRO_PREQ, EPI_STORE)   \
+    /* dim 3072: Llama-3.2-3B, Phi-3.5 */                                                         \
+    X(3072, 32, PRO_RMS_QUANT, EPI_QKV) X(3072, 32, PRO_QUANT, EPI_RESID) X(3072, 16, PRO_RMS_QUANT, EPI_SWIGLU) \
+    X(3072, 16, PRO_RMS_QUANT, EPI_CLS) X(3072, 32, PRO_PREQ, EPI_STORE) X(3072, 16, PRO_PREQ, EPI_STORE) \
+    /* hidden 8192 */                                                                             \
+    X(8192, 32, PRO_QUANT, EPI_RESID) X(8192, 32, PRO_PREQ, EPI_STORE)
+
+static int static_L(const GemvArgs& a, int pro, int epi) {
+    if (a.q4) return 0;
+    // preferred L per (n, o): enough workgroups to cover the chip, rows split over as few clusters as possible
+    int want = 0;
+    if (a.n == 2048) want = a.o >= 8192 ? 8 : 32;
+    else if (a.n == 3072) want = a.o >= 8192 ? 16 : 32;
+    else if (a.n == 8192) want = 32;
+    if (!want) return 0;
+#define X(n_, l_, p_, e_) if (a.n == n_ && want == l_ && pro == p_ && epi == e_) return l_;
+    LMRS_STATIC_TABLE(X)
+#undef X
+    return 0;
+}
+
 static size_t gemv_smem(const GemvArgs& a, int pro) {
     const int n = a.n, G = n / kGS;
     size_t s = ((n + 15) & ~15) + (size_t)((G + 3) & ~3) * 4;
@@ -382,175 +558,232 @@ static size_t gemv_smem(const GemvArgs& a, int pro) {
     return s < 64 ? 64 : s;
 }
 
-// Lanes per row: smallest power of two whose rows are read in <= 16 steps (everything in flight at once).
-static int pick_L(const GemvArgs& a, int epi) {
-    const int row_bytes = a.q4 ? a.n / 2 : a.n;
-    const int cl = a.q4 ? 4 : 8;
-    int L = cl;
-    while (L < 64 && row_bytes / (16 * L) > 16 && row_bytes % (16 * 2 * L) == 0) L *= 2;
-    if ((epi == EPI_SWIGLU || epi == EPI_GELU) && L > 32) L = 32;
-    return L;
+// ---- shape -> (L, U, NP) -----------------------------------------------------------------------
+// L: as few lanes per row as still give >= 256 workgroups (one per CU), because a row split over
+//    several clusters pays NC-1 cross-lane hops in its accumulation chain; valid only if the row's
+//    groups divide evenly over the clusters and (NC > 1) a cluster's groups fit one U-step batch.
+// U: 16-byte steps in flight per lane.  NP: float4 per lane of the activation vector (ceil(n/1024)).
+struct GemvShape { int L, U, NP; };
+
+static GemvShape pick_shape(const GemvArgs& a, int epi) {
+    const int cl = a.q4 ? 4 : 8, G = a.n / kGS;
+    const int NP = a.n <= 2048 ? 2 : (a.n <= 4096 ? 4 : 10);
+    const int maxL = (epi == EPI_SWIGLU || epi == EPI_GELU) ? 32 : 64;
+    int best = cl;
+    for (int L = cl; L <= maxL; L *= 2) {
+        const int NC = L / cl;
+        if (G % NC) continue;
+        const int Gc = G / NC;
+        if (NC > 1 && Gc > 16) continue;
+        best = L;
+        const int RB = (64 / L) * (kBlock / 64);
+        if ((a.o + RB - 1) / RB >= 256) break;
+    }
+    const int NC = best / cl, Gc = G / NC;
+    const int U = NC == 1 ? 16 : (Gc <= 4 ? 4 : (Gc <= 8 ? 8 : 16));
+    return {best, U, NP};
 }
 
-int gemv_grid(const GemvArgs& a, int epi) {
-    const int L = pick_L(a, epi);
-    const int RB = (64 / L) * (kBlock / 64);
+// Instantiated kernels: the classes the supported model shapes map to, plus a generic class per
+// (prologue, epilogue) that handles any n (one cluster per row, NP = 10).
+#define LMRS_GEMV_TABLE(X)                                                                                 \
+    /* generic */                                                                                          \
+    X(8, 16, 10, PRO_PREQ, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_RESID, false) \
+    X(8, 16, 10, PRO_RMS_QUANT, EPI_STORE, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_QKV, false)              \
+    X(8, 16, 10, PRO_RMS_QUANT, EPI_SWIGLU, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_GELU, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_CLS, false) \
+    /* n = 2048 (Llama-3.2-1B dim; Gemma-2-2B att_dim) */                                                  \
+    X(32, 4, 2, PRO_RMS_QUANT, EPI_QKV, false) X(32, 4, 2, PRO_QUANT, EPI_RESID, false) X(32, 4, 2, PRO_QUANT, EPI_STORE, false) \
+    X(8, 16, 2, PRO_RMS_QUANT, EPI_SWIGLU, false) X(8, 16, 2, PRO_RMS_QUANT, EPI_CLS, false) X(8, 16, 2, PRO_RMS_QUANT, EPI_QKV, false) \
+    X(32, 4, 2, PRO_PREQ, EPI_STORE, false) X(8, 16, 2, PRO_PREQ, EPI_STORE, false) X(16, 8, 2, PRO_PREQ, EPI_STORE, false) \
+    /* n = 2304 / 3072 (Gemma-2-2B, Llama-3.2-3B, Phi-3.5 dim) */                                          \
+    X(16, 16, 4, PRO_RMS_QUANT, EPI_QKV, false) X(32, 8, 4, PRO_QUANT, EPI_RESID, false) X(16, 16, 4, PRO_QUANT, EPI_RESID, false) \
+    X(8, 16, 4, PRO_RMS_QUANT, EPI_SWIGLU, false) X(8, 16, 4, PRO_RMS_QUANT, EPI_GELU, false) X(8, 16, 4, PRO_RMS_QUANT, EPI_CLS, false) \
+    X(16, 16, 4, PRO_PREQ, EPI_STORE, false) X(32, 8, 4, PRO_PREQ, EPI_STORE, false)                       \
+    /* n = 8192 / 9216 (hidden_dim) */                                                                     \
+    X(32, 16, 10, PRO_QUANT, EPI_RESID, false) X(32, 16, 10, PRO_QUANT, EPI_STORE, false) X(64, 16, 10, PRO_QUANT, EPI_STORE, false) \
+    X(64, 16, 10, PRO_QUANT, EPI_RESID, false) X(32, 16, 10, PRO_PREQ, EPI_STORE, false) X(64, 16, 10, PRO_PREQ, EPI_STORE, false) \
+    /* Q4_0: generic classes per cluster layout */                                                         \
+    X(4, 16, 10, PRO_PREQ, EPI_STORE, true) X(4, 16, 10, PRO_QUANT, EPI_STORE, true) X(4, 16, 10, PRO_QUANT, EPI_RESID, true) \
+    X(4, 16, 10, PRO_RMS_QUANT, EPI_STORE, true) X(4, 16, 10, PRO_RMS_QUANT, EPI_QKV, true) X(4, 16, 10, PRO_RMS_QUANT, EPI_SWIGLU, true) \
+    X(4, 16, 10, PRO_RMS_QUANT, EPI_GELU, true) X(4, 16, 10, PRO_RMS_QUANT, EPI_CLS, true)                 \
+    X(16, 4, 10, PRO_PREQ, EPI_STORE, true) X(16, 4, 10, PRO_QUANT, EPI_RESID, true) X(16, 4, 10, PRO_QUANT, EPI_STORE, true) \
+    X(16, 4, 10, PRO_RMS_QUANT, EPI_QKV, true) X(16, 16, 10, PRO_QUANT, EPI_RESID, true) X(16, 16, 10, PRO_QUANT, EPI_STORE, true) \
+    X(16, 16, 10, PRO_PREQ, EPI_STORE, true) X(8, 16, 10, PRO_PREQ, EPI_STORE, true) X(8, 16, 10, PRO_RMS_QUANT, EPI_QKV, true)
+
+static bool gemv_instantiated(int L, int U, int NP, int pro, int epi, bool q4) {
+#define X(l, u, np, p, e, q) if (L == l && U == u && NP == np && pro == p && epi == e && q4 == q) return true;
+    LMRS_GEMV_TABLE(X)
+#undef X
+    return false;
+}
+
+static GemvShape resolve_shape(const GemvArgs& a, int pro, int epi) {
+    GemvShape sh = pick_shape(a, epi);
+    if (!gemv_instantiated(sh.L, sh.U, sh.NP, pro, epi, a.q4 != 0)) {
+        if (gemv_instantiated(sh.L, sh.U, 10, pro, epi, a.q4 != 0)) sh.NP = 10;
+        else sh = {a.q4 ? 4 : 8, 16, 10};
+    }
+    return sh;
+}
+
+int gemv_grid(const GemvArgs& a, int pro, int epi) {
+    const int sl = static_L(a, pro, epi);
+    const GemvShape sh = sl ? GemvShape{sl, 0, 0} : resolve_shape(a, pro, epi);
+    const int RB = (64 / sh.L) * (kBlock / 64);
     const int n_pass = (a.o + RB - 1) / RB;
-    const int cap = (epi == EPI_CLS) ? 2048 : 4096;        // classifier: persistent-ish grid, prologue paid once per WG
+    const int cap = (epi == EPI_CLS) ? 512 : 4096;        // classifier: persistent-style grid, prologue paid once per workgroup
     return n_pass < cap ? n_pass : cap;
 }
 
-template <int L, int U, int NP, bool Q4>
-static hipError_t launch_LU(const GemvArgs& a, int pro, int epi, int grid, size_t smem, hipStream_t s) {
-#define LMRS_CASE(P, E)                                                                           \
-    if (pro == P && epi == E) {                                                                   \
-        hipLaunchKernelGGL((gemv_kernel<L, U, NP, P, E, Q4>), dim3(grid), dim3(kBlock), smem, s, a); \
-        return hipGetLastError();                                                                 \
+hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint) {
+    if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
+    const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
+    const size_t smem = gemv_smem(a, pro);
+    if (const int sl = static_L(a, pro, epi)) {
+        if (epi == EPI_CLS && a.softcap_rows) return hipErrorInvalidValue;      // static classes carry Llama/Phi glue only
+#define X(n_, l_, p_, e_)                                                                                  \
+        if (a.n == n_ && sl == l_ && pro == p_ && epi == e_) {                                             \
+            hipLaunchKernelGGL((gemv_static_kernel<n_, l_, p_, e_>), dim3(grid), dim3(kBlock), smem, s, a); \
+            return hipGetLastError();                                                                      \
+        }
+        LMRS_STATIC_TABLE(X)
+#undef X
     }
-    LMRS_CASE(PRO_PREQ, EPI_STORE)
-    LMRS_CASE(PRO_QUANT, EPI_STORE)
-    LMRS_CASE(PRO_QUANT, EPI_RESID)
-    LMRS_CASE(PRO_RMS_QUANT, EPI_STORE)
-    LMRS_CASE(PRO_RMS_QUANT, EPI_QKV)
-    LMRS_CASE(PRO_RMS_QUANT, EPI_SWIGLU)
-    LMRS_CASE(PRO_RMS_QUANT, EPI_GELU)
-    LMRS_CASE(PRO_RMS_QUANT, EPI_CLS)
-#undef LMRS_CASE
+    const GemvShape sh = resolve_shape(a, pro, epi);
+#define X(l, u, np, p, e, q)                                                                               \
+    if (sh.L == l && sh.U == u && sh.NP == np && pro == p && epi == e && (a.q4 != 0) == q) {              \
+        hipLaunchKernelGGL((gemv_kernel<l, u, np, p, e, q>), dim3(grid), dim3(kBlock), smem, s, a);        \
+        return hipGetLastError();                                                                          \
+    }
+    LMRS_GEMV_TABLE(X)
+#undef X
     return hipErrorInvalidValue;
 }
 
-// (L, NP) classes that get their own instantiation; NP = float4 per lane of the activation vector
-// (ceil(n/1024)): keeping it a compile-time constant keeps the prologue's registers proportional to n.
-hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint) {
-    if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
-    const int L = pick_L(a, epi);
-    const int P = (a.n + 1023) / 1024;
-    const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, epi);
-    const size_t smem = gemv_smem(a, pro);
-#define LMRS_TRY(LL, PP, QQ) if (L == LL && P <= PP) return launch_LU<LL, 16, PP, QQ>(a, pro, epi, grid, smem, s);
-    if (!a.q4) {
-        LMRS_TRY(8, 1, false) LMRS_TRY(8, 2, false) LMRS_TRY(8, 10, false)
-        LMRS_TRY(16, 3, false) LMRS_TRY(16, 4, false) LMRS_TRY(16, 10, false)
-        LMRS_TRY(32, 8, false) LMRS_TRY(32, 10, false)
-        LMRS_TRY(64, 10, false)
-    } else {
-        LMRS_TRY(4, 2, true) LMRS_TRY(4, 10, true) LMRS_TRY(8, 3, true) LMRS_TRY(8, 10, true)
-        LMRS_TRY(16, 8, true) LMRS_TRY(16, 10, true) LMRS_TRY(32, 10, true) LMRS_TRY(64, 10, true)
+constexpr int kAttF4 = 16;           // float4 per lane per chunk: CH * HS / 4 / 256 <= 16
+
+// rows t0 .. t0+ct of one kv head (row stride kv_dim floats) -> registers, 16 B per lane per load, coalesced per row
+template <int HS>
+__device__ __forceinline__ void att_gload(float4 (&rg)[kAttF4], const float* __restrict__ base, int t0, int T, int CH, int kv_dim) {
+    constexpr int HS4 = HS / 4;
+    const int ct = (T - t0) < CH ? (T - t0) : CH, nf = ct * HS4;
+#pragma unroll
+    for (int i = 0; i < kAttF4; ++i) {
+        const int f = (int)threadIdx.x + i * kBlock;
+        const int row = f / HS4, c4 = f - row * HS4;
+        rg[i] = f < nf ? *reinterpret_cast<const float4*>(base + (size_t)(t0 + row) * kv_dim + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-#undef LMRS_TRY
-    return hipErrorInvalidValue;
+}
+// registers -> LDS tile (row stride HS + 4 floats); optionally scaled per row (V phase: products a_t * v_t[d])
+template <int HS, bool SCALE>
+__device__ __forceinline__ void att_tstore(const float4 (&rg)[kAttF4], float* tile, const float* rowscale, int t0, int T, int CH, int skip_t) {
+    constexpr int HS4 = HS / 4, RS = HS + 4;
+    const int ct = (T - t0) < CH ? (T - t0) : CH;
+    // V phase: also write rows ct .. ceil16(ct)-1 (registers hold zeros there and the zero-padded weights scale
+    // them by +0.0), so that the serial chain can run in full batches of 16
+    const int nf = (SCALE ? ((ct + 15) & ~15) : ct) * HS4;
+#pragma unroll
+    for (int i = 0; i < kAttF4; ++i) {
+        const int f = (int)threadIdx.x + i * kBlock;
+        const int row = f / HS4, c4 = f - row * HS4;
+        if (f < nf && t0 + row != skip_t) {
+            float4 v = rg[i];
+            if constexpr (SCALE) { const float a = rowscale[row]; v.x = a * v.x; v.y = a * v.y; v.z = a * v.z; v.w = a * v.w; }
+            *reinterpret_cast<float4*>(tile + row * RS + c4 * 4) = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Attention for one new token: RoPE + scores + softmax + weighted V  (transformer.rs:443-544)
-// One workgroup per query head.  Softmax's sum and the V accumulation are sequential over t in the
-// reference and float addition is not associative, so each stays one serial chain on one lane;
-// everything order-free (scores across t, max, exp, divide, the hs output dims) is parallel.
-// The K and V rows of the head are staged through LDS in chunks of CH timesteps (CH*hs = 16384 floats):
-// all 256 lanes issue their global loads up front (K and V of the first chunk together, before RoPE),
-// so the chains never wait on a global load; the next chunk's loads are in flight while the current one
-// is consumed.
+// One workgroup per query head, head size HS a compile-time constant.  Softmax's sum and the V
+// accumulation are sequential over t in the reference and float addition is not associative, so each
+// stays one serial chain of ADDS on one lane; everything order-free runs in parallel: the scores across
+// t, max, exp, divide, the HS output dims, and the products a_t * v_t[d] (formed by all 256 lanes when the
+// V tile is written to LDS, so the serial part is add-only).
+// K and V rows are staged through LDS in chunks of CH timesteps (CH*HS = 16384 floats); all lanes issue
+// their global loads up front (K and V of the first chunk together, before RoPE); the next chunk's loads
+// are in flight while the current one is consumed.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAttF4 = 16;           // float4 per lane per chunk: CH * hs / 4 / 256 <= 16
+#define ATT_STAMP(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
 
-// rows t0 .. t0+ct of one kv head (row stride kv_dim floats) -> registers, 16 B per lane per load, coalesced per row
-__device__ __forceinline__ void att_gload(float4 (&rg)[kAttF4], const float* __restrict__ base, int t0, int T, int CH, int hs4, int kv_dim) {
-    const int ct = (T - t0) < CH ? (T - t0) : CH, nf = ct * hs4;
-#pragma unroll
-    for (int i = 0; i < kAttF4; ++i) {
-        const int f = (int)threadIdx.x + i * kBlock;
-        const int row = f / hs4, c4 = f - row * hs4;
-        rg[i] = f < nf ? *reinterpret_cast<const float4*>(base + (size_t)(t0 + row) * kv_dim + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-__device__ __forceinline__ void att_tstore(const float4 (&rg)[kAttF4], float* tile, int t0, int T, int CH, int hs4, int RS, int skip_t) {
-    const int ct = (T - t0) < CH ? (T - t0) : CH, nf = ct * hs4;
-#pragma unroll
-    for (int i = 0; i < kAttF4; ++i) {
-        const int f = (int)threadIdx.x + i * kBlock;
-        const int row = f / hs4, c4 = f - row * hs4;
-        if (f < nf && t0 + row != skip_t) *reinterpret_cast<float4*>(tile + row * RS + c4 * 4) = rg[i];
-    }
-}
-
+template <int HS>
 __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int hs = a.head_size, half = hs >> 1, hs4 = hs >> 2, RS = hs + 4;
+    constexpr int half = HS / 2, HS4 = HS / 4, RS = HS + 4;
     const int h = blockIdx.x, kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
-    const int kv_dim = a.n_kv_heads * hs;
+    const int kv_dim = a.n_kv_heads * HS;
+    ATT_STAMP(0);
     const int pos = a.st->pos, T = pos + 1;
     const int tid = threadIdx.x;
     const int CH = a.chunk;
-    float* q = reinterpret_cast<float*>(smem);        // hs
-    float* kn = q + hs;                               // hs: rotated key of this position
-    float* red = kn + hs;                             // 16 floats of reduction scratch
-    float* tile = red + 16;                           // CH rows of RS floats (RS = hs + 4: conflict-free float4 row reads)
-    float* att = tile + (size_t)CH * RS;              // T
+    float* q = reinterpret_cast<float*>(smem);        // HS
+    float* kn = q + HS;                               // HS: rotated key of this position
+    float* red = kn + HS;                             // 16 floats of reduction scratch
+    float* tile = red + 16;                           // CH rows of RS floats (RS = HS + 4: conflict-free float4 row reads)
+    float* att = tile + (size_t)(CH + 16) * RS;       // T (+32 floats of zero padding)
     const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
     const int nchunks = (T + CH - 1) / CH;
 
+    const uint64_t etab = exp2f_tab_lane();
     float4 kreg[kAttF4], vreg[kAttF4];
-    const float* kbase = a.k_cache + loff + kvh * hs;
-    const float* vbase = a.v_cache + loff + kvh * hs;
-    att_gload(kreg, kbase, 0, T, CH, hs4, kv_dim);   // row `pos` of K is not in the cache yet (patched from kn below); its load is harmless
-    att_gload(vreg, vbase, 0, T, CH, hs4, kv_dim);   // row `pos` of V was stored by the QKV kernel
+    const float* kbase = a.k_cache + loff + kvh * HS;
+    const float* vbase = a.v_cache + loff + kvh * HS;
+    att_gload<HS>(kreg, kbase, 0, T, CH, kv_dim);   // row `pos` of K is not in the cache yet (patched from kn below); its load is harmless
+    att_gload<HS>(vreg, vbase, 0, T, CH, kv_dim);   // row `pos` of V was stored by the QKV kernel
+    ATT_STAMP(1);
 
     // RoPE (transformer.rs:480-491) with the host-built (fcr, fci) table
     for (int j = tid; j < half; j += kBlock) {
         const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
         const float fcr = cs.x, fci = cs.y;
         {
-            const float v0 = a.q[h * hs + j], v1 = a.q[h * hs + j + half];
+            const float v0 = a.q[h * HS + j], v1 = a.q[h * HS + j + half];
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
             q[j] = a0 - a1; q[j + half] = b0 + b1;
         }
         {
-            const float v0 = a.k_raw[kvh * hs + j], v1 = a.k_raw[kvh * hs + j + half];
+            const float v0 = a.k_raw[kvh * HS + j], v1 = a.k_raw[kvh * HS + j + half];
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
             const float r0 = a0 - a1, r1 = b0 + b1;
             kn[j] = r0; kn[j + half] = r1;
             if (h % kv_mul == 0) {                   // one writer per kv head
-                a.k_cache[loff + (size_t)pos * kv_dim + kvh * hs + j] = r0;
-                a.k_cache[loff + (size_t)pos * kv_dim + kvh * hs + j + half] = r1;
+                a.k_cache[loff + (size_t)pos * kv_dim + kvh * HS + j] = r0;
+                a.k_cache[loff + (size_t)pos * kv_dim + kvh * HS + j + half] = r1;
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    ATT_STAMP(2);
 
     // scores (transformer.rs:507-529): one lane per t, sequential dot over the head dims
-    const float sqrt_hs = sqrtf((float)hs);
+    const float sqrt_hs = sqrtf((float)HS);
     float lmax = __uint_as_float(0xff800000u);
     for (int c = 0; c < nchunks; ++c) {
         const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore(kreg, tile, t0, T, CH, hs4, RS, pos);
-        if (pos >= t0 && pos < t0 + ct && tid < hs4)
+        att_tstore<HS, false>(kreg, tile, nullptr, t0, T, CH, pos);
+        if (pos >= t0 && pos < t0 + ct && tid < HS4)
             *reinterpret_cast<float4*>(tile + (pos - t0) * RS + tid * 4) = *reinterpret_cast<const float4*>(kn + tid * 4);
-        __syncthreads();
-        if (c + 1 < nchunks) att_gload(kreg, kbase, t0 + CH, T, CH, hs4, kv_dim);
+        lds_barrier();
+        if (c + 1 < nchunks) att_gload<HS>(kreg, kbase, t0 + CH, T, CH, kv_dim);
+        if (c == 0) ATT_STAMP(3);
         if (tid < ct) {
             const float4* kr = reinterpret_cast<const float4*>(tile + tid * RS);
+            const float4* qr = reinterpret_cast<const float4*>(q);
             float score = 0.0f;
-            for (int d4 = 0; d4 < hs4; d4 += 4) {              // hs % 16 == 0 is not required: guarded below
-                float4 k0 = kr[d4], k1 = d4 + 1 < hs4 ? kr[d4 + 1] : k0, k2 = d4 + 2 < hs4 ? kr[d4 + 2] : k0, k3 = d4 + 3 < hs4 ? kr[d4 + 3] : k0;
-                const float4 q0 = *reinterpret_cast<const float4*>(q + d4 * 4);
-                float pr;
-                pr = q0.x * k0.x; score = score + pr; pr = q0.y * k0.y; score = score + pr;
-                pr = q0.z * k0.z; score = score + pr; pr = q0.w * k0.w; score = score + pr;
-                if (d4 + 1 < hs4) {
-                    const float4 q1 = *reinterpret_cast<const float4*>(q + d4 * 4 + 4);
-                    pr = q1.x * k1.x; score = score + pr; pr = q1.y * k1.y; score = score + pr;
-                    pr = q1.z * k1.z; score = score + pr; pr = q1.w * k1.w; score = score + pr;
-                }
-                if (d4 + 2 < hs4) {
-                    const float4 q2 = *reinterpret_cast<const float4*>(q + d4 * 4 + 8);
-                    pr = q2.x * k2.x; score = score + pr; pr = q2.y * k2.y; score = score + pr;
-                    pr = q2.z * k2.z; score = score + pr; pr = q2.w * k2.w; score = score + pr;
-                }
-                if (d4 + 3 < hs4) {
-                    const float4 q3 = *reinterpret_cast<const float4*>(q + d4 * 4 + 12);
-                    pr = q3.x * k3.x; score = score + pr; pr = q3.y * k3.y; score = score + pr;
-                    pr = q3.z * k3.z; score = score + pr; pr = q3.w * k3.w; score = score + pr;
-                }
+#pragma unroll
+            for (int d0 = 0; d0 < HS4; d0 += 16) {                 // 16 x 16 B of the row in flight, then 64 serial adds
+                float4 kk[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (d0 + u < HS4) kk[u] = kr[d0 + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (d0 + u < HS4) {
+                        const float4 qq = qr[d0 + u];
+                        float pr;
+                        pr = qq.x * kk[u].x; score = score + pr; pr = qq.y * kk[u].y; score = score + pr;
+                        pr = qq.z * kk[u].z; score = score + pr; pr = qq.w * kk[u].w; score = score + pr;
+                    }
             }
             score = score / sqrt_hs;
             if (a.gemma) {                                 // transformer.rs:518-526
@@ -562,57 +795,66 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
             att[t0 + tid] = score;
             lmax = fmaxf(lmax, score);
         }
-        __syncthreads();
+        lds_barrier();
     }
+    ATT_STAMP(4);
     // softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
     if ((tid & 63) == 0) red[tid >> 6] = lmax;
-    __syncthreads();
+    lds_barrier();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    for (int t = tid; t < T; t += kBlock) att[t] = expf_glibc(att[t] - mx);
-    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += kBlock) {                  // whole waves call expf together (it shuffles)
+        const int t = t0 + tid;
+        const float e = expf_glibc_t(t < T ? att[t] - mx : 0.0f, etab);
+        if (t < T) att[t] = e;
+    }
+    if (tid < 32) att[T + tid] = 0.0f;                       // +0.0 padding for the batched serial sum
+    lds_barrier();
     if (tid == 0) {
+        // serial sum (functional.rs:134).  Reads are issued 32 ahead of the chain; the ragged tail is padded with
+        // +0.0 (exact: the running sum of exponentials is >= +0), so there is no one-LDS-read-per-add tail loop.
         float sum = 0.0f;
-        int t = 0;
-        for (; t + 16 <= T; t += 16) {                     // 16 LDS reads in flight per batch of 16 serial adds
-            float e[16];
+        for (int t = 0; t < T; t += 32) {                  // att[T .. T+31] was zero-padded above
+            float4 e[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) e[u] = att[t + u];
+            for (int u = 0; u < 8; ++u) e[u] = *reinterpret_cast<const float4*>(att + t + u * 4);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) sum = sum + e[u];
+            for (int u = 0; u < 8; ++u) { sum = sum + e[u].x; sum = sum + e[u].y; sum = sum + e[u].z; sum = sum + e[u].w; }
         }
-        for (; t < T; ++t) sum = sum + att[t];
         red[4] = sum;
     }
-    __syncthreads();
+    lds_barrier();
     const float sum = red[4];
     for (int t = tid; t < T; t += kBlock) att[t] = att[t] / sum;
-    // (the barrier inside the chunk loop below orders these writes before the reads)
+    lds_barrier();
+    ATT_STAMP(5);
 
-    // weighted sum of values (transformer.rs:533-541): one lane per output dim, sequential over t
+    // weighted sum of values (transformer.rs:533-541): products a_t * v_t[d] by all lanes into the tile, then one
+    // lane per output dim adds them up sequentially over t
     float o = 0.0f;
     for (int c = 0; c < nchunks; ++c) {
         const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore(vreg, tile, t0, T, CH, hs4, RS, -1);
-        __syncthreads();
-        if (c + 1 < nchunks) att_gload(vreg, vbase, t0 + CH, T, CH, hs4, kv_dim);
-        if (tid < hs) {
+        att_tstore<HS, true>(vreg, tile, att + t0, t0, T, CH, -1);
+        lds_barrier();
+        if (c + 1 < nchunks) att_gload<HS>(vreg, vbase, t0 + CH, T, CH, kv_dim);
+        if (c == 0) ATT_STAMP(6);
+        if (tid < HS) {
             const float* vc = tile + tid;
-            const float* at = att + t0;
-            int t = 0;
-            for (; t + 8 <= ct; t += 8) {
-                float vv[8], aa[8];
+            // serial chain of adds over t; 16 LDS reads in flight per batch; tail padded with +0.0 (exact: the
+            // accumulator starts at +0.0 and can never become -0.0)
+            for (int t = 0; t < ct; t += 16) {                 // rows ct .. ct+15 of the tile are zero (att_tstore)
+                float pv[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { vv[u] = vc[(t + u) * RS]; aa[u] = at[t + u]; }
+                for (int u = 0; u < 16; ++u) pv[u] = vc[(t + u) * RS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const float pr = aa[u] * vv[u]; o = o + pr; }
+                for (int u = 0; u < 16; ++u) o = o + pv[u];
             }
-            for (; t < ct; ++t) { const float pr = at[t] * vc[t * RS]; o = o + pr; }
         }
-        __syncthreads();
+        lds_barrier();
     }
-    if (tid < hs) a.out[h * hs + tid] = o;
+    if (tid < HS) a.out[h * HS + tid] = o;
+    ATT_STAMP(7);
 }
 
 int attention_chunk(int head_size) {
@@ -621,18 +863,29 @@ int attention_chunk(int head_size) {
     return ch < 32 ? 32 : ch;
 }
 
+template <int HS>
+static hipError_t launch_attention_hs(const AttnArgs& a, size_t smem, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_kernel<HS>, dim3(a.n_heads), dim3(kBlock), smem, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     a.chunk = attention_chunk(a.head_size);
-    if (a.head_size > 256 || a.head_size % 4 || a.chunk * (a.head_size / 4) > kAttF4 * kBlock) return hipErrorInvalidValue;
-    const size_t smem = (size_t)(2 * a.head_size + 16 + (size_t)a.chunk * (a.head_size + 4) + ((a.seq_len + 3) & ~3)) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    if (a.chunk * (a.head_size / 4) > kAttF4 * kBlock) return hipErrorInvalidValue;
+    const size_t smem = (size_t)(2 * a.head_size + 16 + (size_t)(a.chunk + 16) * (a.head_size + 4) + ((a.seq_len + 3) & ~3) + 32) * 4;
+    switch (a.head_size) {                                      // head sizes of the supported model families
+        case 64: return launch_attention_hs<64>(a, smem, s);    // Llama-3.2-1B, tiny test models
+        case 96: return launch_attention_hs<96>(a, smem, s);    // Phi-3.5
+        case 128: return launch_attention_hs<128>(a, smem, s);  // Llama-3.2-3B
+        case 256: return launch_attention_hs<256>(a, smem, s);  // Gemma-2
+        default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(attention_kernel, dim3(a.n_heads), dim3(kBlock), smem, s, a);
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -678,6 +931,8 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
     __shared__ float sv[kBlock];
     __shared__ int si[kBlock];
     __shared__ uint32_t s_next;
+    LMRS_STAMP(0);
+    if (a.dbg && threadIdx.x == 0) a.dbg[1] = clock64();          // shader-clock cycles, to derive the running clock
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
     for (int i = threadIdx.x; i < a.n_part; i += kBlock) {
         const float v = a.part_val[i]; const int idx = a.part_idx[i];
@@ -712,6 +967,8 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
         if (a.emb.do_scale) v = v * a.emb.scale;
         a.emb.x[i] = v;
     }
+    LMRS_STAMP(3);
+    if (a.dbg && threadIdx.x == 0) a.dbg[2] = clock64();
 }
 
 hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s) {

@@ -1,0 +1,233 @@
+// lmrs_stage.h — fully static (compile-time shape) building blocks of the decode path, shared by the
+// per-stage kernels (lmrs_kernels.hip) and by the persistent decode engine (lmrs_engine.hip).
+//
+// Why static: with the vector length N, the lanes-per-row L and the steps-per-lane U known at compile
+// time there is not a single data-dependent branch around a global load, so hipcc keeps *counted*
+// s_waitcnt vmcnt(k) waits: the activation loads (issued first) can be consumed while the whole weight
+// tile issued right after them is still in flight.  (With runtime trip counts the compiler falls back to
+// vmcnt(0) before the first LDS write and the prologue serialises behind the weight stream.)
+//
+// Arithmetic: identical, operation for operation, to the generic kernels (see lmrs_kernels.hip header).
+#pragma once
+#include "lmrs_device_math.h"
+#include "lmrs_kernels.h"
+
+namespace lmrs {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));     // native vector: what the nontemporal builtin accepts
+constexpr int kBlk = 256;
+
+// ------------------------------------------------------------------------------------------------
+// Memory flavours.  COH = data exchanged between workgroups INSIDE one launch (persistent engine):
+// agent-scope relaxed atomics (global_load/store ... sc1), which bypass the per-CU L1 and are written
+// through, so no fences (a fence would also drain the in-flight weight tiles).  !COH = data produced by
+// an earlier launch: plain accesses.
+// ------------------------------------------------------------------------------------------------
+template <bool COH> __device__ __forceinline__ float ld_f32(const float* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH> __device__ __forceinline__ void st_f32(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH> __device__ __forceinline__ float4 ld_f32x4(const float* p) {
+    if constexpr (COH) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                           __uint_as_float((unsigned)(b >> 32)));
+    } else return *reinterpret_cast<const float4*>(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Activation vector in registers: thread t owns elements i*1024 + 4t .. +3, i < NP = ceil(N/1024)
+// (32 consecutive lanes own one 128-element quantisation group).
+// ------------------------------------------------------------------------------------------------
+template <int N> struct VecGeom {
+    static constexpr int NP = (N + 1023) / 1024;
+    static constexpr bool FULL = (N % 1024) == 0;
+    static constexpr int G = N / 128;
+};
+
+template <int N, bool COH>
+__device__ __forceinline__ void vec_load(float4 (&v)[VecGeom<N>::NP], const float* __restrict__ x) {
+    constexpr int NP = VecGeom<N>::NP;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = i * 1024 + (int)threadIdx.x * 4;
+        if (VecGeom<N>::FULL || i < NP - 1 || e < N) v[i] = ld_f32x4<COH>(x + e);
+        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// RMSNorm (reference functional.rs:48-78), in place on v[]; nw[] = norm weights of the same elements.
+// scratch: 8 * (N/8 + 4) + 4 floats of LDS.
+template <int N>
+__device__ __forceinline__ void vec_rmsnorm(float4 (&v)[VecGeom<N>::NP], const float4 (&nw)[VecGeom<N>::NP], float eps, int add_unit, float* scratch) {
+    constexpr int NP = VecGeom<N>::NP, JP = N / 8 + 4, NJ4 = N / 32;
+    static_assert(N % 256 == 0, "N must be a multiple of 256");
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = i * 1024 + t * 4;
+        if (VecGeom<N>::FULL || i < NP - 1 || e < N) {
+            const int j = e >> 3, k0 = e & 7;
+            scratch[(k0 + 0) * JP + j] = v[i].x * v[i].x;
+            scratch[(k0 + 1) * JP + j] = v[i].y * v[i].y;
+            scratch[(k0 + 2) * JP + j] = v[i].z * v[i].z;
+            scratch[(k0 + 3) * JP + j] = v[i].w * v[i].w;
+        }
+    }
+    lds_barrier();
+    if (t < 64) {
+        // lanes 0..7: the 8 strided partial sums (ss_sim += x*x), each a serial chain of N/8 adds; the LDS
+        // reads run 4 x 16 B ahead of the chain (ping-pong batches).
+        float p = 0.0f;
+        if (t < 8) {
+            const float4* row = reinterpret_cast<const float4*>(scratch + t * JP);
+            float4 A[4], B[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) A[u] = row[u];
+#pragma unroll
+            for (int j0 = 0; j0 < NJ4; j0 += 8) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) B[u] = row[j0 + 4 + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
+                if (j0 + 8 < NJ4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) A[u] = row[j0 + 8 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
+            }
+        }
+        const float p0 = __shfl(p, 0), p1 = __shfl(p, 1), p2 = __shfl(p, 2), p3 = __shfl(p, 3);
+        const float p4 = __shfl(p, 4), p5 = __shfl(p, 5), p6 = __shfl(p, 6), p7 = __shfl(p, 7);
+        if (t == 0) {
+            float ss = reduce_add8(p0, p1, p2, p3, p4, p5, p6, p7);
+            ss = ss / (float)N;
+            ss = ss + eps;
+            ss = 1.0f / sqrtf(ss);
+            scratch[8 * JP] = ss;
+        }
+    }
+    lds_barrier();
+    const float ss = scratch[8 * JP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        float4 o;
+        if (add_unit) {
+            o.x = (1.0f + nw[i].x) * (ss * v[i].x); o.y = (1.0f + nw[i].y) * (ss * v[i].y);
+            o.z = (1.0f + nw[i].z) * (ss * v[i].z); o.w = (1.0f + nw[i].w) * (ss * v[i].w);
+        } else {
+            o.x = nw[i].x * (ss * v[i].x); o.y = nw[i].y * (ss * v[i].y);
+            o.z = nw[i].z * (ss * v[i].z); o.w = nw[i].w * (ss * v[i].w);
+        }
+        v[i] = o;
+    }
+}
+
+// quantize (reference quantization.rs:44-67) of v[] into LDS: xq[N] int8, xs[N/128] f32.
+template <int N>
+__device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[VecGeom<N>::NP], int8_t* xq, float* xs) {
+    constexpr int NP = VecGeom<N>::NP;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = i * 1024 + t * 4;
+        const bool live = VecGeom<N>::FULL || i < NP - 1 || e < N;
+        float m = live ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.0f;
+        m = group32_max(m);
+        if (live) {
+            const float scale = m / 127.0f;
+            const int q0 = quant_q8(v[i].x, scale), q1 = quant_q8(v[i].y, scale);
+            const int q2 = quant_q8(v[i].z, scale), q3 = quant_q8(v[i].w, scale);
+            *reinterpret_cast<unsigned*>(xq + e) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
+            if ((t & 31) == 0) xs[e >> 7] = scale;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight tile: the 16-byte steps one lane holds for one row-pass (Q8_0).
+//   L lanes per row, NC = L/8 clusters, each cluster owns a contiguous segment of U = G/NC groups.
+// ------------------------------------------------------------------------------------------------
+template <int N, int L> struct RowGeom {
+    static constexpr int G = N / 128, NC = L / 8, U = G / NC;
+    static constexpr int RW = 64 / L, RB = RW * (kBlk / 64);      // rows per wave / per workgroup pass
+    static_assert(G % NC == 0, "row groups must divide over the clusters");
+    static_assert(U >= 1 && U <= 24, "a cluster's groups must fit one tile");
+};
+
+template <int U> struct WTile { i32x4 w[U]; float sc[U]; };
+
+template <int N, int L>
+__device__ __forceinline__ void tile_issue(WTile<RowGeom<N, L>::U>& t, const int8_t* __restrict__ wq, const float* __restrict__ ws, int row) {
+    using R = RowGeom<N, L>;
+    const int lane = threadIdx.x & 63, r = lane % L, g0 = (r / 8) * R::U, rc = r & 7;
+    const i32x4* wrow = reinterpret_cast<const i32x4*>(wq + (size_t)row * N) + g0 * 8 + rc;
+    const float* srow = ws + (size_t)row * R::G + g0;
+#pragma unroll
+    for (int u = 0; u < R::U; ++u) {
+        t.w[u] = __builtin_nontemporal_load(wrow + u * 8);
+        t.sc[u] = srow[u];
+    }
+}
+
+// -> the row's result, valid in the lanes of the row's LAST cluster (r >= L - 8).
+template <int N, int L>
+__device__ __forceinline__ float tile_consume(const WTile<RowGeom<N, L>::U>& t, const int8_t* xq, const float* xs) {
+    using R = RowGeom<N, L>;
+    const int lane = threadIdx.x & 63, r = lane % L, cl = r / 8, g0 = cl * R::U, rc = r & 7;
+    float pb[R::U];
+#pragma unroll
+    for (int u = 0; u < R::U; ++u) {
+        const i32x4 x = *reinterpret_cast<const i32x4*>(xq + ((g0 + u) * 8 + rc) * 16);
+        int d = __builtin_amdgcn_sdot4(t.w[u].x, x.x, 0, false);
+        d = __builtin_amdgcn_sdot4(t.w[u].y, x.y, d, false);
+        d = __builtin_amdgcn_sdot4(t.w[u].z, x.z, d, false);
+        d = __builtin_amdgcn_sdot4(t.w[u].w, x.w, d, false);
+        d = cluster8_sum(d);
+        float p = (float)d * t.sc[u];                 // (ival as f32) * w.s[..]
+        pb[u] = p * xs[g0 + u];                       //   * x.s[..]
+    }
+    float acc = 0.0f;
+    if constexpr (R::NC == 1) {
+#pragma unroll
+        for (int u = 0; u < R::U; ++u) acc = acc + pb[u];                    // xout += ..., groups ascending
+    } else {
+#pragma unroll
+        for (int j = 0; j < R::NC; ++j) {
+            const float carry = j == 0 ? 0.0f : __shfl(acc, (lane & ~(L - 1)) + (j - 1) * 8);
+            if (cl == j) {
+                acc = carry;
+#pragma unroll
+                for (int u = 0; u < R::U; ++u) acc = acc + pb[u];
+            }
+        }
+    }
+    return acc;
+}
+
+// SiLU(gate) * up, reference transformer.rs:617-620
+__device__ __forceinline__ float swiglu(float gate, float up) {
+    const float e = expf_glibc(-gate);
+    const float g = 1.0f / (1.0f + e);
+    float val = gate * g;
+    val = val * up;
+    return val;
+}
+
+// same, expf table fetched by lane shuffle: every lane of the wave must call it
+__device__ __forceinline__ float swiglu_t(float gate, float up, uint64_t lane_tab) {
+    const float e = expf_glibc_t(-gate, lane_tab);
+    const float g = 1.0f / (1.0f + e);
+    float val = gate * g;
+    val = val * up;
+    return val;
+}
+
+}  // namespace lmrs

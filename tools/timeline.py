@@ -1,0 +1,46 @@
+"""Per-kernel timeline of one decode step from the in-kernel wall-clock stamps (LMRS_DEBUG_TIMELINE=1).
+usage: LMRS_DEBUG_TIMELINE=1 python tools/timeline.py [model] [pos]"""
+import os
+import sys
+
+os.environ["LMRS_DEBUG_TIMELINE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import lmrs_amd  # noqa: E402
+from tools import synth_lmrs as S  # noqa: E402
+
+model = sys.argv[1] if len(sys.argv) > 1 else "llama-3.2-1b"
+npos = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+img = S.build_image(model, S.Q8_0, 1234)
+m = lmrs_amd.Transformer(img)
+prompt = S.prompt_tokens(model, 16, 1234)
+toks, sec = m.generate_greedy(prompt, npos - 15, timing=True)
+print(f"{(16 + npos - 16) / sec:.0f} tok/s over {npos} steps")
+tl = m.debug_timeline().astype(np.int64)
+names = ["qkv", "attn", "wo", "w13", "w2"]
+t0 = tl[0, 0]
+print("node  name   start  | first WG: pro   pass1  end   | last WG: start pro pass1 end | gap_to_next   (us, 10ns clock)")
+L = (len(tl) - 2) // 5
+tot = {}
+for i, r in enumerate(tl):
+    name = names[i % 5] if i < 5 * L else ("cls" if i == 5 * L else "argmax")
+    f = (r[:4] - r[0]) / 100.0
+    l = (r[4:] - r[0]) / 100.0
+    end = max(r[3], r[7])
+    nxt = tl[i + 1, 0] if i + 1 < len(tl) else end
+    dur = (end - r[0]) / 100.0
+    tot.setdefault(name, []).append((dur, (nxt - end) / 100.0, f[1], f[2] - f[1]))
+    if i < 10 or i >= len(tl) - 3:
+        print(f"{i:3d} {name:6s} {(r[0]-t0)/100.0:8.2f} | {f[1]:6.2f} {f[2]:6.2f} {f[3]:6.2f} | {l[0]:6.2f} {l[1]:6.2f} {l[2]:6.2f} {l[3]:6.2f} | {(nxt-end)/100.0:6.2f}")
+print("\nmean per kernel type: duration(us)  gap_after(us)  prologue(us)  first-pass(us)")
+for k, v in tot.items():
+    a = np.array(v)
+    print(f"  {k:7s} n={len(v):3d}  {a[:,0].mean():7.2f} {a[:,1].mean():7.2f} {a[:,2].mean():7.2f} {a[:,3].mean():7.2f}")
+att = tl[1::5][:L]
+d = (att - att[:, :1]) / 100.0
+print("attention block0 stamps (us from start): loads-issued, rope-done, k-in-lds, scores-done, softmax-done, v-in-lds, end")
+print("   ", np.round(d[:, [1, 2, 3, 4, 5, 6, 7]].mean(axis=0), 2))
+am = tl[-1]
+print(f"shader clock during argmax kernel: {(am[2]-am[1]) / ((am[3]-am[0]) / 100.0):.0f} MHz")
+print(f"step span: {(max(tl[-1,3], tl[-1,7]) - t0)/100.0:.1f} us")

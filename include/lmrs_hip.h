@@ -64,6 +64,13 @@ int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, i
 /* Writes the 128-byte ncclUniqueId for lmrs_create_sharded (call on rank 0). */
 int lmrs_comm_unique_id(void* out128);
 
+/* Verification aid (no reference counterpart): `world` row shards of one model as `world` contexts on ONE device,
+ * exchanged by device-to-device copies instead of RCCL, so the sharding can be checked bit for bit on a 1-GPU box. */
+int lmrs_group_create(const uint8_t* file, size_t len, int device, int world, lmrs_ctx** shards, size_t* bytes_consumed);
+/* One decode step over such a group.  *logits (optional) = the assembled logits (pinned, owned by shards[0]);
+ * *next (optional) = the greedy token. */
+int lmrs_group_forward(lmrs_ctx** shards, int world, uint32_t token, uint32_t pos, float** logits, uint32_t* next);
+
 /* Drop for Transformer (src/transformer.rs:688-712). */
 void lmrs_destroy(lmrs_ctx* ctx);
 

@@ -28,6 +28,7 @@ EXPORTS = [
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
     "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline",
+    "lmrs_group_create", "lmrs_group_forward",
 ]
 
 
@@ -80,6 +81,8 @@ def lib():
         L.lmrs_bench_gemv.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.lmrs_step_info.argtypes = [vp, u32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.lmrs_debug_timeline.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.lmrs_group_create.argtypes = [vp, sz, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.lmrs_group_forward.argtypes = [C.POINTER(vp), C.c_int, u32, u32, C.POINTER(f32p), C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -107,7 +110,7 @@ class Transformer:
     def __init__(self, data, device: int = 0, rank: int = 0, world: int = 1, unique_id: bytes | None = None):
         image = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8)
         h, used = C.c_void_p(), C.c_size_t()
-        if world == 1:
+        if world == 1 and unique_id is None:
             _chk(lib().lmrs_create(_p(image), image.size, device, C.byref(h), C.byref(used)))
         else:
             uid = C.create_string_buffer(unique_id, 128) if unique_id else None
@@ -173,6 +176,37 @@ class Transformer:
         n, b = C.c_int(), C.c_double()
         _chk(lib().lmrs_step_info(self._h, pos, C.byref(n), C.byref(b)))
         return n.value, b.value
+
+
+def comm_unique_id() -> bytes:
+    """128-byte ncclUniqueId for Transformer(..., world > 1): make it on rank 0, broadcast it to the other ranks."""
+    buf = C.create_string_buffer(128)
+    _chk(lib().lmrs_comm_unique_id(buf))
+    return buf.raw
+
+
+class ShardGroup:
+    """`world` row shards of one model on ONE device (verification aid: the multi-GPU partitioning without RCCL)."""
+
+    def __init__(self, data, world: int, device: int = 0):
+        image = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8)
+        self._arr = (C.c_void_p * world)()
+        used = C.c_size_t()
+        _chk(lib().lmrs_group_create(_p(image), image.size, device, world, self._arr, C.byref(used)))
+        self.world = world
+        self.args = lib().lmrs_get_args(self._arr[0]).contents
+
+    def forward(self, token: int, pos: int):
+        p, n = C.POINTER(C.c_float)(), C.c_uint32()
+        _chk(lib().lmrs_group_forward(self._arr, self.world, token, pos, C.byref(p), C.byref(n)))
+        return np.ctypeslib.as_array(p, shape=(self.args.vocab_size,)), n.value
+
+    def close(self):
+        for i in range(self.world):
+            if self._arr[i]:
+                lib().lmrs_destroy(self._arr[i]); self._arr[i] = None
+
+    __del__ = close
 
 
 # ---- free functions (functional.rs / quantization.rs), each on the device kernels

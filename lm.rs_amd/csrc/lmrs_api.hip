@@ -17,6 +17,7 @@
 //   activations x[dim], q[att], k_raw[kv], att_out[att], h[hidden], logits[vocab], argmax partials,
 //   tokens[seq_len+1], DevState
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,7 +60,7 @@ struct lmrs_ctx {
     char* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;
     std::vector<DevLayer> layers;
     const void *emb_q = nullptr, *cls_q = nullptr; const float *emb_s = nullptr, *cls_s = nullptr, *rms_final = nullptr;
-    float *x = nullptr, *q = nullptr, *k_raw = nullptr, *att_out = nullptr, *h = nullptr, *logits = nullptr;
+    float *x = nullptr, *q = nullptr, *k_raw = nullptr, *att_out = nullptr, *h = nullptr, *logits = nullptr, *tmp = nullptr;
     float *part_val = nullptr; int* part_idx = nullptr;
     float *k_cache = nullptr, *v_cache = nullptr, *rope = nullptr;
     float* stage = nullptr; size_t stage_floats = 0;        // device staging for fill_kv_cache / get_embeddings
@@ -69,8 +70,17 @@ struct lmrs_ctx {
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int att_dim = 0, kv_dim = 0, cls_grid = 0;
+    int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
     bool q4 = false;
+    // ---- row sharding.  Every shard owns whole output rows, so every float accumulation chain
+    // lives on one GPU and results are bit-identical to world == 1.
+    int rank = 0, world = 1;
+    int att_full = 0;                              // n_heads * head_size of the whole model
+    int dim_l = 0, hid_l = 0, voc_l = 0;           // rows of wo/w2, gate-up pairs of w13, classifier rows owned here
+    int d0 = 0, h0 = 0, v0 = 0, a0 = 0;            // first owned row / pair / vocab row / att column
+    ncclComm_t comm = nullptr;                     // RCCL communicator (one process per GPU); null in group mode
+    bool eager = false;                            // sharded step could not be captured: enqueue it every call
+    float* part = nullptr;                         // [world][values(cls_grid) | indices(cls_grid)] argmax partials
 
     template <class T> T* alloc(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -141,17 +151,19 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_attention(t, c->stream));
     // 3. quantize | Wo | x += ...                                       (:550-576)
-    g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = c->x;
+    g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-    HIP_OK(launch_gemv(g, PRO_QUANT, EPI_RESID, c->stream));
+    HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
+    if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
-    g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h;
+    g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_SWIGLU, c->stream));
+    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
     // 5. quantize | W2 | x += ...                                       (:630-654)
-    g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = c->x;
+    g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-    HIP_OK(launch_gemv(g, PRO_QUANT, EPI_RESID, c->stream));
+    HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
+    if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));   // :643-650
     return 0;
 }
 
@@ -159,8 +171,14 @@ GemvArgs cls_args(lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     GemvArgs g{};
     g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = a.model_type == LMRS_GEMMA; g.st = c->st;
-    g.wq = c->cls_q; g.ws = c->cls_s; g.n = a.dim; g.o = a.vocab_size; g.xin = c->x; g.rms_w = c->rms_final;
-    g.out = c->logits; g.part_val = c->part_val; g.part_idx = c->part_idx;
+    const size_t row_bytes = c->q4 ? a.dim / 2 : a.dim;
+    g.wq = static_cast<const char*>(c->cls_q) + (size_t)c->v0 * row_bytes; g.ws = c->cls_s + (size_t)c->v0 * (a.dim / 128);
+    g.n = a.dim; g.o = c->voc_l; g.xin = c->x; g.rms_w = c->rms_final; g.row_offset = c->v0;
+    g.out = c->logits + c->v0;
+    if (c->world > 1 || c->comm) {          // sharded: this shard's [values | indices] block of the gathered partials
+        g.part_val = c->part + (size_t)c->rank * 2 * c->cls_grid;
+        g.part_idx = reinterpret_cast<int*>(c->part + (size_t)c->rank * 2 * c->cls_grid) + c->cls_grid;
+    } else { g.part_val = c->part_val; g.part_idx = c->part_idx; }
     g.softcap_rows = a.model_type == LMRS_GEMMA ? (int)a.dim : 0;
     return g;
 }
@@ -183,9 +201,107 @@ int enqueue_step(lmrs_ctx* c) {
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
     ArgmaxArgs m{};
-    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c);
+    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c);
     m.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_argmax_final(m, c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-sharded step (world > 1), cut into segments at the points where every shard needs the others' rows.
+//   segment 4l+0: [x += tmp] qkv(own heads) -> attention(own heads)      then gather att_out   (att/W per shard)
+//   segment 4l+1: wo (own rows)                                          then gather tmp       (dim/W)
+//   segment 4l+2: x += tmp ; w1/w3 (own pairs) -> silu*up                 then gather h         (hidden/W)
+//   segment 4l+3: w2 (own rows)                                          then gather tmp       (dim/W)
+//   segment 4L  : x += tmp ; classifier (own vocab rows) + argmax partials  then gather partials
+//   segment 4L+1: argmax over all shards' partials, next-token embedding (replicated)
+// Gathers are in place: shard r's slice sits at buf + r * count on every shard.
+// ------------------------------------------------------------------------------------------------
+struct GatherDesc { float* buf; size_t count; };
+
+int n_segments(const lmrs_ctx* c) { return 4 * (int)c->args.n_layers + 2; }
+
+GatherDesc gather_after(lmrs_ctx* c, int seg) {
+    const int L4 = 4 * (int)c->args.n_layers;
+    if (seg < L4) {
+        switch (seg & 3) {
+            case 0: return {c->att_out, (size_t)c->att_dim};
+            case 1: return {c->tmp, (size_t)c->dim_l};
+            case 2: return {c->h, (size_t)c->hid_l};
+            default: return {c->tmp, (size_t)c->dim_l};
+        }
+    }
+    if (seg == L4) return {c->part, (size_t)2 * c->cls_grid};
+    return {nullptr, 0};
+}
+
+int run_segment(lmrs_ctx* c, int seg) {
+    const lmrs_args& a = c->args;
+    const int L4 = 4 * (int)a.n_layers;
+    if (a.model_type == LMRS_GEMMA) return fail("row sharding of the GEMMA variant is not built");
+    GemvArgs g{};
+    g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = 0; g.st = c->st;
+    if (seg < L4) {
+        const int l = seg >> 2; const DevLayer& L = c->layers[l];
+        switch (seg & 3) {
+            case 0: {
+                if (l > 0) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+                g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
+                g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
+                g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
+                HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_QKV, c->stream));
+                AttnArgs t{};
+                t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope;
+                t.out = c->att_out + c->a0;
+                t.n_heads = c->att_dim / a.head_size; t.n_kv_heads = c->kv_dim / a.head_size; t.head_size = a.head_size;
+                t.seq_len = a.seq_len; t.layer = l; t.gemma = 0; t.st = c->st;
+                HIP_OK(launch_attention(t, c->stream));
+                break;
+            }
+            case 1:
+                g.wq = L.wo; g.ws = L.so; g.n = c->att_full; g.o = c->dim_l; g.xin = c->att_out; g.out = c->tmp + c->d0;
+                HIP_OK(launch_gemv(g, PRO_QUANT, EPI_STORE, c->stream));
+                break;
+            case 2:
+                HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+                g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * c->hid_l; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h + c->h0;
+                HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_SWIGLU, c->stream));
+                break;
+            default:
+                g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = c->dim_l; g.xin = c->h; g.out = c->tmp + c->d0;
+                HIP_OK(launch_gemv(g, PRO_QUANT, EPI_STORE, c->stream));
+                break;
+        }
+        return 0;
+    }
+    if (seg == L4) {
+        HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+        GemvArgs k = cls_args(c);
+        HIP_OK(launch_gemv(k, PRO_RMS_QUANT, EPI_CLS, c->stream));
+        return 0;
+    }
+    ArgmaxArgs m{};
+    m.part_val = c->part; m.part_idx = reinterpret_cast<const int*>(c->part) + c->cls_grid; m.n_part = c->cls_grid;
+    m.n_groups = c->world; m.group_stride = 2 * c->cls_grid;
+    m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c);
+    HIP_OK(launch_argmax_final(m, c->stream));
+    return 0;
+}
+
+#define NCCL_OK(expr)                                                                                    \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail(std::string(#expr) + ": " + ncclGetErrorString(r_));          \
+    } while (0)
+
+// the whole sharded step on this shard's stream, RCCL all-gathers between the segments
+int enqueue_step_sharded(lmrs_ctx* c) {
+    const int ns = n_segments(c);
+    for (int s = 0; s < ns; ++s) {
+        if (run_segment(c, s)) return -1;
+        const GatherDesc gd = gather_after(c, s);
+        if (gd.buf) NCCL_OK(ncclAllGather(gd.buf + (size_t)c->rank * gd.count, gd.buf, gd.count, ncclFloat, c->comm, c->stream));
+    }
     return 0;
 }
 
@@ -194,7 +310,7 @@ int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out) {
     c->dbg_node = 0;
     HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
-    if (full) rc = enqueue_step(c);
+    if (full) rc = c->world > 1 || c->comm ? enqueue_step_sharded(c) : enqueue_step(c);
     else {
         for (uint32_t l = 0; l < c->args.n_layers && !rc; ++l) rc = enqueue_layer(c, (int)l);
         if (!rc) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
@@ -227,16 +343,86 @@ int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end) {
 
 }  // namespace
 
-extern "C" int lmrs_comm_unique_id(void* out128) { (void)out128; return fail("row-sharded multi-GPU path is not built in this round"); }
+extern "C" int lmrs_comm_unique_id(void* out128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    if (!out128) return fail("out128 is NULL");
+    ncclUniqueId id;
+    NCCL_OK(ncclGetUniqueId(&id));
+    memcpy(out128, &id, sizeof id);
+    return 0;
+}
+
+static int create_impl(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid, bool group_mode,
+                       lmrs_ctx** out, size_t* bytes_consumed);
 
 extern "C" int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid,
                                    lmrs_ctx** out, size_t* bytes_consumed) {
-    (void)uid;
-    if (world != 1 || rank != 0) return fail("row-sharded multi-GPU path is not built in this round (world must be 1)");
-    return lmrs_create(file, len, device, out, bytes_consumed);
+    if (world < 1 || rank < 0 || rank >= world) return fail("bad rank/world");
+    if (world > 1 && !uid) return fail("world > 1 needs the ncclUniqueId made by lmrs_comm_unique_id on rank 0");
+    return create_impl(file, len, device, rank, world, uid, false, out, bytes_consumed);
 }
 
 extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx** out, size_t* bytes_consumed) {
+    return create_impl(file, len, device, 0, 1, nullptr, false, out, bytes_consumed);
+}
+
+// Verification aid (no reference counterpart): `world` row shards of one model as `world` contexts on ONE device,
+// exchanged by device-to-device copies instead of RCCL, so that the sharding can be checked bit for bit on a
+// single-GPU box.  shards[] receives `world` contexts; drive them with lmrs_group_forward.
+extern "C" int lmrs_group_create(const uint8_t* file, size_t len, int device, int world, lmrs_ctx** shards, size_t* bytes_consumed) {
+    if (world < 1 || !shards) return fail("bad argument");
+    for (int r = 0; r < world; ++r) shards[r] = nullptr;
+    for (int r = 0; r < world; ++r)
+        if (create_impl(file, len, device, r, world, nullptr, true, &shards[r], bytes_consumed)) {
+            for (int k = 0; k < r; ++k) { lmrs_destroy(shards[k]); shards[k] = nullptr; }
+            return -1;
+        }
+    return 0;
+}
+
+// One decode step over the shard group (segments in lockstep, slices exchanged by copies).  *logits (optional) = the
+// assembled full logits on shard 0's pinned buffer; *next (optional) = the greedy token.
+extern "C" int lmrs_group_forward(lmrs_ctx** sh, int world, uint32_t token, uint32_t pos, float** logits, uint32_t* next) {
+    if (!sh || world < 1 || !sh[0]) return fail("bad argument");
+    lmrs_ctx* c0 = sh[0];
+    if (token >= c0->args.vocab_size) return fail("token out of range");
+    if (pos >= c0->args.seq_len) return fail("pos out of range (seq_len is clamped to 8192)");
+    HIP_OK(hipSetDevice(c0->device));
+    for (int r = 0; r < world; ++r) {
+        lmrs_ctx* c = sh[r];
+        if (c->world != world || c->rank != r || c->comm) return fail("contexts are not a shard group made by lmrs_group_create");
+        c->h_tok[0] = token;
+        HIP_OK(hipMemcpyAsync(c->tokens + pos, c->h_tok, 4, hipMemcpyHostToDevice, c->stream));
+        if (set_state(c, pos, 0)) return -1;
+        HIP_OK(launch_embed(embed_args(c), c->stream));
+    }
+    const int ns = n_segments(c0);
+    for (int s = 0; s < ns; ++s) {
+        for (int r = 0; r < world; ++r) if (run_segment(sh[r], s)) return -1;
+        HIP_OK(hipDeviceSynchronize());
+        const GatherDesc g0 = gather_after(c0, s);
+        if (!g0.buf) continue;
+        for (int dst = 0; dst < world; ++dst)
+            for (int src = 0; src < world; ++src) {
+                if (src == dst) continue;
+                const GatherDesc gs = gather_after(sh[src], s), gd = gather_after(sh[dst], s);
+                HIP_OK(hipMemcpyAsync(gd.buf + (size_t)src * gd.count, gs.buf + (size_t)src * gs.count, gs.count * 4, hipMemcpyDeviceToDevice, sh[dst]->stream));
+            }
+        HIP_OK(hipDeviceSynchronize());
+    }
+    if (logits) {
+        for (int r = 0; r < world; ++r)
+            HIP_OK(hipMemcpyAsync(c0->h_logits + sh[r]->v0, sh[r]->logits + sh[r]->v0, (size_t)sh[r]->voc_l * 4, hipMemcpyDeviceToHost, c0->stream));
+        *logits = c0->h_logits;
+    }
+    if (next) HIP_OK(hipMemcpyAsync(c0->h_tok + 1, c0->tokens + pos + 1, 4, hipMemcpyDeviceToHost, c0->stream));
+    HIP_OK(hipDeviceSynchronize());
+    if (next) *next = c0->h_tok[1];
+    return 0;
+}
+
+static int create_impl(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid, bool group_mode,
+                       lmrs_ctx** out, size_t* bytes_consumed) {
     if (!out) return fail("out is NULL");
     *out = nullptr;
     Layout lay; std::string perr;
@@ -244,7 +430,6 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     const lmrs_args& a = lay.args;
     if (a.q_type == LMRS_Q_NONE) return fail("q_type None (f32 weights) is not on the HIP hot path; quantised LMRS files only");
     if (a.group_size != 128) return fail("group_size != 128 is not supported by the HIP kernels (the reference exporter always quantises with 128)");
-    if (a.model_type == LMRS_GEMMA) return fail("GEMMA glue (post-norms) not built yet in the HIP path");
     const size_t dim = a.dim, att = (size_t)a.n_heads * a.head_size, kv = (size_t)a.n_kv_heads * a.head_size, hid = a.hidden_dim, V = a.vocab_size;
     if (dim % 128 || att % 128 || hid % 128) return fail("dim, n_heads*head_size and hidden_dim must be multiples of 128");
     if (dim > 10240 || att > 10240 || hid > 10240) return fail("vector length above 10240 not supported");
@@ -255,13 +440,31 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     if (device < 0 || device >= ndev) return fail("bad device index");
     HIP_OK(hipSetDevice(device));
 
+    // ---- shard plan: whole heads / rows per shard, equal sizes (in-place all-gathers need equal counts)
+    const size_t W = (size_t)world;
+    if (world > 1 && (a.n_kv_heads % W || dim % W || hid % W || V % W))
+        return fail("world must divide n_kv_heads, dim, hidden_dim and vocab_size");
+    const size_t hs = a.head_size;
+    const size_t att_l = att / W, kv_l = kv / W, dim_l = dim / W, hid_l = hid / W, voc_l = V / W;
+    const size_t a0 = rank * att_l, k0 = rank * kv_l, d0 = rank * dim_l, h0 = rank * hid_l, v0 = rank * voc_l;
+    (void)hs;
+
     lmrs_ctx* c = new lmrs_ctx();
-    c->args = a; c->lay = lay; c->device = device; c->att_dim = (int)att; c->kv_dim = (int)kv; c->q4 = a.q_type == LMRS_Q4_0;
+    c->args = a; c->lay = lay; c->device = device; c->q4 = a.q_type == LMRS_Q4_0;
+    c->rank = rank; c->world = world; c->att_full = (int)att;
+    c->att_dim = (int)att_l; c->kv_dim = (int)kv_l; c->dim_l = (int)dim_l; c->hid_l = (int)hid_l; c->voc_l = (int)voc_l;
+    c->a0 = (int)a0; c->d0 = (int)d0; c->h0 = (int)h0; c->v0 = (int)v0;
+    const bool sharded = world > 1 || uid != nullptr;
     auto cleanup = [&]() { lmrs_destroy(c); return -1; };
 #define CK(call) do { if ((call)) return cleanup(); } while (0)
 #define HCK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return cleanup(); } } while (0)
     HCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HCK(hipEventCreate(&c->ev0)); HCK(hipEventCreate(&c->ev1));
+    if (sharded && !group_mode) {
+        ncclUniqueId id; memcpy(&id, uid, sizeof id);
+        ncclResult_t nr = ncclCommInitRank(&c->comm, world, id, rank);
+        if (nr != ncclSuccess) { fail(std::string("ncclCommInitRank: ") + ncclGetErrorString(nr)); return cleanup(); }
+    }
 
     const size_t G = 128, bpe_num = c->q4 ? 1 : 2;   // bytes per element = bpe_num / 2
     auto qbytes = [&](size_t rows, size_t cols) { return rows * cols * bpe_num / 2; };
@@ -270,52 +473,56 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     size_t total = 0;
     auto need = [&](size_t b) { total += pad256(b); };
     for (size_t l = 0; l < nl; ++l) {
-        need(qbytes(att + 2 * kv, dim)); need(sbytes(att + 2 * kv, dim));
-        need(qbytes(dim, att)); need(sbytes(dim, att));
-        need(qbytes(2 * hid, dim)); need(sbytes(2 * hid, dim));
-        need(qbytes(dim, hid)); need(sbytes(dim, hid));
+        need(qbytes(att_l + 2 * kv_l, dim)); need(sbytes(att_l + 2 * kv_l, dim));
+        need(qbytes(dim_l, att)); need(sbytes(dim_l, att));
+        need(qbytes(2 * hid_l, dim)); need(sbytes(2 * hid_l, dim));
+        need(qbytes(dim_l, hid)); need(sbytes(dim_l, hid));
         for (int i = 0; i < 4; ++i) need(dim * 4);
     }
     need(qbytes(V, dim)); need(sbytes(V, dim));
     if (a.model_type == LMRS_PHI) { need(qbytes(V, dim)); need(sbytes(V, dim)); }
     need(dim * 4);
-    const size_t kvn = nl * a.seq_len * kv;
+    const size_t kvn = nl * a.seq_len * kv_l;
     need(kvn * 4); need(kvn * 4);
     need((size_t)a.seq_len * a.head_size * 4);                               // rope table
-    need(dim * 4); need(att * 4); need(kv * 4); need(att * 4); need(hid * 4); need(V * 4);
-    need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4);
+    need(dim * 4); need(att_l * 4); need(kv_l * 4); need(att * 4); need(hid * 4); need(V * 4); need(dim * 4);
+    need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4); need(W * 2 * kMaxArgmaxParts * 4);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
     c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8);
     total += 4096;
     HCK(hipMalloc(reinterpret_cast<void**>(&c->arena), total));
     c->arena_bytes = total;
 
-    // ---- weights
+    // ---- weights: this shard's rows only (the embedding / classifier table stays whole: any row may be looked up)
+    auto upload_rows = [&](void* dst, const TensorView& tv, size_t row0, size_t nrows, size_t cols, bool scales) -> int {
+        const size_t rb = scales ? cols / G * 4 : qbytes(1, cols);
+        return upload(c, dst, file + (scales ? tv.s_off : tv.q_off) + row0 * rb, nrows * rb);
+    };
     c->layers.resize(nl);
     for (size_t l = 0; l < nl; ++l) {
         DevLayer& D = c->layers[l];
-        char* wqkv = c->alloc<char>(qbytes(att + 2 * kv, dim)); float* sqkv = c->alloc<float>(sbytes(att + 2 * kv, dim) / 4);
-        char* wo = c->alloc<char>(qbytes(dim, att)); float* so = c->alloc<float>(sbytes(dim, att) / 4);
-        char* w13 = c->alloc<char>(qbytes(2 * hid, dim)); float* s13 = c->alloc<float>(sbytes(2 * hid, dim) / 4);
-        char* w2 = c->alloc<char>(qbytes(dim, hid)); float* s2 = c->alloc<float>(sbytes(dim, hid) / 4);
+        char* wqkv = c->alloc<char>(qbytes(att_l + 2 * kv_l, dim)); float* sqkv = c->alloc<float>(sbytes(att_l + 2 * kv_l, dim) / 4);
+        char* wo = c->alloc<char>(qbytes(dim_l, att)); float* so = c->alloc<float>(sbytes(dim_l, att) / 4);
+        char* w13 = c->alloc<char>(qbytes(2 * hid_l, dim)); float* s13 = c->alloc<float>(sbytes(2 * hid_l, dim) / 4);
+        char* w2 = c->alloc<char>(qbytes(dim_l, hid)); float* s2 = c->alloc<float>(sbytes(dim_l, hid) / 4);
         float* r0 = c->alloc<float>(dim); float* r1 = c->alloc<float>(dim); float* r2 = c->alloc<float>(dim); float* r3 = c->alloc<float>(dim);
         if (!wqkv || !sqkv || !wo || !so || !w13 || !s13 || !w2 || !s2 || !r3) { fail("arena overflow"); return cleanup(); }
         const TensorView &tq = lay.wq[l], &tk = lay.wk[l], &tv = lay.wv[l];
-        CK(upload(c, wqkv, file + tq.q_off, tq.q_bytes));
-        CK(upload(c, wqkv + tq.q_bytes, file + tk.q_off, tk.q_bytes));
-        CK(upload(c, wqkv + tq.q_bytes + tk.q_bytes, file + tv.q_off, tv.q_bytes));
-        CK(upload(c, sqkv, file + tq.s_off, tq.s_bytes));
-        CK(upload(c, reinterpret_cast<char*>(sqkv) + tq.s_bytes, file + tk.s_off, tk.s_bytes));
-        CK(upload(c, reinterpret_cast<char*>(sqkv) + tq.s_bytes + tk.s_bytes, file + tv.s_off, tv.s_bytes));
-        CK(upload(c, wo, file + lay.wo[l].q_off, lay.wo[l].q_bytes));
-        CK(upload(c, so, file + lay.wo[l].s_off, lay.wo[l].s_bytes));
         const size_t rb = qbytes(1, dim), srb = dim / G * 4;
-        CK(upload_interleaved(c, w13, file + lay.w1[l].q_off, rb, hid, 0));
-        CK(upload_interleaved(c, w13, file + lay.w3[l].q_off, rb, hid, 1));
-        CK(upload_interleaved(c, s13, file + lay.w1[l].s_off, srb, hid, 0));
-        CK(upload_interleaved(c, s13, file + lay.w3[l].s_off, srb, hid, 1));
-        CK(upload(c, w2, file + lay.w2[l].q_off, lay.w2[l].q_bytes));
-        CK(upload(c, s2, file + lay.w2[l].s_off, lay.w2[l].s_bytes));
+        CK(upload_rows(wqkv, tq, a0, att_l, dim, false));
+        CK(upload_rows(wqkv + att_l * rb, tk, k0, kv_l, dim, false));
+        CK(upload_rows(wqkv + (att_l + kv_l) * rb, tv, k0, kv_l, dim, false));
+        CK(upload_rows(sqkv, tq, a0, att_l, dim, true));
+        CK(upload_rows(reinterpret_cast<char*>(sqkv) + att_l * srb, tk, k0, kv_l, dim, true));
+        CK(upload_rows(reinterpret_cast<char*>(sqkv) + (att_l + kv_l) * srb, tv, k0, kv_l, dim, true));
+        CK(upload_rows(wo, lay.wo[l], d0, dim_l, att, false));
+        CK(upload_rows(so, lay.wo[l], d0, dim_l, att, true));
+        CK(upload_interleaved(c, w13, file + lay.w1[l].q_off + h0 * rb, rb, hid_l, 0));
+        CK(upload_interleaved(c, w13, file + lay.w3[l].q_off + h0 * rb, rb, hid_l, 1));
+        CK(upload_interleaved(c, s13, file + lay.w1[l].s_off + h0 * srb, srb, hid_l, 0));
+        CK(upload_interleaved(c, s13, file + lay.w3[l].s_off + h0 * srb, srb, hid_l, 1));
+        CK(upload_rows(w2, lay.w2[l], d0, dim_l, hid, false));
+        CK(upload_rows(s2, lay.w2[l], d0, dim_l, hid, true));
         CK(upload(c, r0, file + lay.rms_att[l].q_off, dim * 4));
         CK(upload(c, r1, file + lay.rms_post_att[l].q_off, dim * 4));
         if (a.model_type == LMRS_GEMMA) {
@@ -331,10 +538,10 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
         CK(upload(c, eq, file + lay.emb.q_off, lay.emb.q_bytes)); CK(upload(c, es, file + lay.emb.s_off, lay.emb.s_bytes));
         c->emb_q = eq; c->emb_s = es; c->cls_q = eq; c->cls_s = es;        // tied classifier = the QUANTISED table
         if (a.model_type == LMRS_PHI) {
-            char* hq = c->alloc<char>(lay.lm_head.q_bytes); float* hs = c->alloc<float>(lay.lm_head.s_bytes / 4);
-            if (!hq || !hs) { fail("arena overflow"); return cleanup(); }
-            CK(upload(c, hq, file + lay.lm_head.q_off, lay.lm_head.q_bytes)); CK(upload(c, hs, file + lay.lm_head.s_off, lay.lm_head.s_bytes));
-            c->cls_q = hq; c->cls_s = hs;
+            char* hq = c->alloc<char>(lay.lm_head.q_bytes); float* hsx = c->alloc<float>(lay.lm_head.s_bytes / 4);
+            if (!hq || !hsx) { fail("arena overflow"); return cleanup(); }
+            CK(upload(c, hq, file + lay.lm_head.q_off, lay.lm_head.q_bytes)); CK(upload(c, hsx, file + lay.lm_head.s_off, lay.lm_head.s_bytes));
+            c->cls_q = hq; c->cls_s = hsx;
         }
         float* rf = c->alloc<float>(dim);
         CK(upload(c, rf, file + lay.rms_final.q_off, dim * 4));
@@ -343,9 +550,10 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
     // ---- state
     c->k_cache = c->alloc<float>(kvn); c->v_cache = c->alloc<float>(kvn);
     c->rope = c->alloc<float>((size_t)a.seq_len * a.head_size);
-    c->x = c->alloc<float>(dim); c->q = c->alloc<float>(att); c->k_raw = c->alloc<float>(kv); c->att_out = c->alloc<float>(att);
-    c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V);
+    c->x = c->alloc<float>(dim); c->q = c->alloc<float>(att_l); c->k_raw = c->alloc<float>(kv_l); c->att_out = c->alloc<float>(att);
+    c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V); c->tmp = c->alloc<float>(dim);
     c->part_val = c->alloc<float>(kMaxArgmaxParts); c->part_idx = c->alloc<int>(kMaxArgmaxParts);
+    c->part = c->alloc<float>(W * 2 * kMaxArgmaxParts);
     c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
     if (getenv("LMRS_DEBUG_TIMELINE")) { c->dbg = c->alloc<unsigned long long>(8 * 1024); if (c->dbg) HCK(hipMemsetAsync(c->dbg, 0, 8 * 1024 * 8, c->stream)); }
     c->stage = c->alloc<float>(c->stage_floats);
@@ -370,8 +578,13 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
         GemvArgs g = cls_args(c);
         c->cls_grid = gemv_grid(g, PRO_RMS_QUANT, EPI_CLS);
     }
-    CK(capture(c, true, &c->g_step));
-    CK(capture(c, false, &c->g_layers));
+    if (!sharded) {
+        CK(capture(c, true, &c->g_step));
+        CK(capture(c, false, &c->g_layers));
+    } else if (!group_mode) {
+        // RCCL collectives inside a captured graph: use it when the runtime accepts it, else enqueue every step
+        if (capture(c, true, &c->g_step)) { c->g_step = nullptr; c->eager = true; (void)hipGetLastError(); g_err.clear(); }
+    }
 #undef CK
 #undef HCK
     *out = c;
@@ -385,6 +598,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->g_step) hipGraphExecDestroy(c->g_step);
     if (c->g_layers) hipGraphExecDestroy(c->g_layers);
+    if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) hipHostFree(c->h_logits);
     if (c->h_tok) hipHostFree(c->h_tok);
     if (c->h_st) hipHostFree(c->h_st);
@@ -397,6 +611,13 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
 
 extern "C" const lmrs_args* lmrs_get_args(const lmrs_ctx* c) { return c ? &c->args : nullptr; }
 
+// one decode step on the context's stream: the captured graph, or (sharded, capture refused) eager launches
+static int launch_step(lmrs_ctx* c) {
+    if (c->g_step) { HIP_OK(hipGraphLaunch(c->g_step, c->stream)); return 0; }
+    if (c->comm && c->eager) return enqueue_step_sharded(c);
+    return fail("this context is a member of a shard group: drive it with lmrs_group_forward");
+}
+
 static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
     if (!c) return fail("ctx is NULL");
     if (token >= c->args.vocab_size) return fail("token out of range");
@@ -406,12 +627,12 @@ static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
     HIP_OK(hipMemcpyAsync(c->tokens + pos, c->h_tok, 4, hipMemcpyHostToDevice, c->stream));
     if (set_state(c, pos, 0)) return -1;
     HIP_OK(launch_embed(embed_args(c), c->stream));
-    HIP_OK(hipGraphLaunch(c->g_step, c->stream));
-    return 0;
+    return launch_step(c);
 }
 
 extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** logits) {
     if (step_once(c, token, pos)) return -1;
+    if (c->world > 1) NCCL_OK(ncclAllGather(c->logits + c->v0, c->logits, (size_t)c->voc_l, ncclFloat, c->comm, c->stream));
     HIP_OK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->args.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     if (logits) *logits = c->h_logits;
@@ -446,6 +667,7 @@ extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, s
 extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, uint32_t curr_pos, uint32_t* new_pos) {
     if (!c || !embeddings) return fail("NULL argument");
     if ((size_t)curr_pos + n > c->args.seq_len) return fail("positions out of range");
+    if (!c->g_layers) return fail("fill_kv_cache is not built for row-sharded contexts");
     HIP_OK(hipSetDevice(c->device));
     // forward_layer(sl = n) for every layer is, value for value, n single-token passes through the
     // layers (causal; each token's arithmetic only sees tokens <= itself), so the decode graph is reused.
@@ -474,7 +696,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     if (set_state(c, start_pos, start_pos + (uint32_t)n_prompt)) return -1;
     HIP_OK(hipEventRecord(c->ev0, c->stream));
     HIP_OK(launch_embed(embed_args(c), c->stream));
-    for (size_t s = 0; s < steps; ++s) HIP_OK(hipGraphLaunch(c->g_step, c->stream));
+    for (size_t s = 0; s < steps; ++s) if (launch_step(c)) return -1;
     HIP_OK(hipEventRecord(c->ev1, c->stream));
     if (n_new) HIP_OK(hipMemcpyAsync(c->h_tok, c->tokens + start_pos + n_prompt, (size_t)n_new * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
@@ -489,6 +711,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
 // Infinity Cache), each launch bracketed by HIP events on the context's stream.
 extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* bytes5, int* count5) {
     if (!c || iters <= 0 || !us5 || !bytes5 || !count5) return fail("bad argument");
+    if (c->world > 1 || c->comm) return fail("lmrs_bench_gemv: single-GPU contexts only");
     HIP_OK(hipSetDevice(c->device));
     const lmrs_args& a = c->args;
     const int nl = (int)a.n_layers, n_launch = 4 * nl + 1;
@@ -559,7 +782,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = 5 * (int)a.n_layers + 2;
+    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA ? 7 : 5) * (int)a.n_layers + 2;
     return 0;
 }
 

@@ -32,7 +32,8 @@ struct GemvArgs {
     float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer;
     const DevState* st;
     // EPI_CLS
-    float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on rows < softcap_rows
+    float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on (global) rows < softcap_rows
+    int row_offset;          // global index of this launch's row 0 (row-sharded classifier)
     unsigned long long* dbg; // optional: 8 wall-clock stamps (debug timeline)
 };
 
@@ -57,6 +58,7 @@ struct EmbedArgs {
 
 struct ArgmaxArgs {
     const float* part_val; const int* part_idx; int n_part;
+    int n_groups, group_stride;   // row-sharded classifier: n_groups shards of partials, group_stride entries apart (1 shard: 1, 0)
     const float* logits;
     uint32_t* tokens; DevState* st;
     EmbedArgs emb;           // the winner's (or the next prompt token's) embedding row is written to emb.x
@@ -68,6 +70,8 @@ hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int g
 int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
+hipError_t launch_addvec(float* x, const float* d, int n, hipStream_t st);
+hipError_t launch_addnorm(float* x, const float* delta, const float* w, int n, float eps, hipStream_t st);   // Gemma: x += rmsnorm(delta, 1 + w)
 hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s);
 hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint32_t* tokens, int n_tok, int dim, float* out, hipStream_t st);
 

@@ -391,13 +391,13 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         } else if constexpr (EPI == EPI_CLS) {
             if (valid && r == wlane) {
                 float vv = acc;
-                if (row < a.softcap_rows) {                   // transformer.rs:375-381 (first `dim` logits only)
+                if (row + a.row_offset < a.softcap_rows) {    // transformer.rs:375-381 (first `dim` logits only)
                     vv = vv / 30.0f;
                     vv = (float)tanh((double)vv);
                     vv = vv * 30.0f;
                 }
                 a.out[row] = vv;
-                if (vv > best) { best = vv; best_i = row; }   // rows ascend per lane: first maximum kept
+                if (vv > best) { best = vv; best_i = row + a.row_offset; }   // rows ascend per lane: first maximum kept
             }
         }
     }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
         } else if constexpr (EPI == EPI_CLS) {
             if (valid && writer) {
                 a.out[row] = acc;
-                if (acc > best) { best = acc; best_i = row; }
+                if (acc > best) { best = acc; best_i = row + a.row_offset; }
             }
         }
     };
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
     X(8192, 32, PRO_QUANT, EPI_RESID) X(8192, 32, PRO_PREQ, EPI_STORE)
 
 static int static_L(const GemvArgs& a, int pro, int epi) {
-    if (a.q4) return 0;
+    if (a.q4 || (epi == EPI_CLS && a.softcap_rows)) return 0;     // static classes: Q8_0, Llama/Phi glue
     // preferred L per (n, o): enough workgroups to cover the chip, rows split over as few clusters as possible
     int want = 0;
     if (a.n == 2048) want = a.o >= 8192 ? 8 : 32;
@@ -640,7 +640,6 @@ hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int g
     const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
     const size_t smem = gemv_smem(a, pro);
     if (const int sl = static_L(a, pro, epi)) {
-        if (epi == EPI_CLS && a.softcap_rows) return hipErrorInvalidValue;      // static classes carry Llama/Phi glue only
 #define X(n_, l_, p_, e_)                                                                                  \
         if (a.n == n_ && sl == l_ && pro == p_ && epi == e_) {                                             \
             hipLaunchKernelGGL((gemv_static_kernel<n_, l_, p_, e_>), dim3(grid), dim3(kBlock), smem, s, a); \
@@ -934,8 +933,10 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
     LMRS_STAMP(0);
     if (a.dbg && threadIdx.x == 0) a.dbg[1] = clock64();          // shader-clock cycles, to derive the running clock
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
-    for (int i = threadIdx.x; i < a.n_part; i += kBlock) {
-        const float v = a.part_val[i]; const int idx = a.part_idx[i];
+    // partials: n_groups shards x n_part entries; shard g holds [values | indices] at part_val + g * group_stride
+    for (int i = threadIdx.x; i < a.n_part * a.n_groups; i += kBlock) {
+        const int g = i / a.n_part, k = i - g * a.n_part;
+        const float v = a.part_val[(size_t)g * a.group_stride + k]; const int idx = a.part_idx[(size_t)g * a.group_stride + k];
         if (v > best || (v == best && idx < best_i)) { best = v; best_i = idx; }
     }
     sv[threadIdx.x] = best; si[threadIdx.x] = best_i;
@@ -1016,6 +1017,49 @@ hipError_t launch_rmsnorm(const float* x, const float* w, float* o, int n, float
     if (n % 32 || n > kMaxP * 1024) return hipErrorInvalidValue;
     const size_t smem = (size_t)(8 * (n / 8 + 4) + 4) * 4;
     hipLaunchKernelGGL(rmsnorm_kernel, dim3(1), dim3(kBlock), smem, st, x, w, o, n, eps, add_unit);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gemma glue (transformer.rs:563-568, 643-650): x += rmsnorm(delta, w, add_unit_offset = true).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void addnorm_kernel(float* x, const float* delta, const float* w, int n, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 v[kMaxP], nw[kMaxP];
+    load_vec(v, delta, n);
+    load_vec(nw, w, n);
+    rmsnorm_inplace(v, nw, n, eps, 1, reinterpret_cast<float*>(smem));
+    const int P = (n + 1023) >> 10;
+#pragma unroll
+    for (int i = 0; i < kMaxP; ++i)
+        if (i < P) {
+            const int e = i * 1024 + threadIdx.x * 4;
+            if (e < n) {
+                float4 xv = *reinterpret_cast<const float4*>(x + e);
+                xv.x = xv.x + v[i].x; xv.y = xv.y + v[i].y; xv.z = xv.z + v[i].z; xv.w = xv.w + v[i].w;
+                *reinterpret_cast<float4*>(x + e) = xv;
+            }
+        }
+}
+
+hipError_t launch_addnorm(float* x, const float* delta, const float* w, int n, float eps, hipStream_t st) {
+    if (n % 32 || n > kMaxP * 1024) return hipErrorInvalidValue;
+    const size_t smem = (size_t)(8 * (n / 8 + 4) + 4) * 4;
+    hipLaunchKernelGGL(addnorm_kernel, dim3(1), dim3(kBlock), smem, st, x, delta, w, n, eps);
+    return hipGetLastError();
+}
+
+// x[i] += d[i]  (row-sharded path: the residual add after the all-gather of a projection's slices)
+__global__ void addvec_kernel(float* x, const float* d, int n) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i < n) {
+        float4 a = *reinterpret_cast<const float4*>(x + i); const float4 b = *reinterpret_cast<const float4*>(d + i);
+        a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+        *reinterpret_cast<float4*>(x + i) = a;
+    }
+}
+hipError_t launch_addvec(float* x, const float* d, int n, hipStream_t st) {
+    hipLaunchKernelGGL(addvec_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, st, x, d, n);
     return hipGetLastError();
 }
 

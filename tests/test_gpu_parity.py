@@ -124,7 +124,7 @@ def test_matmul_q4(L, n, o):
 
 
 # ------------------------------------------------------------------ whole path, golden fixtures
-GOLDEN = ["tiny_llama_q8", "tiny_llama_q4", "tiny_phi_q8"]
+GOLDEN = ["tiny_llama_q8", "tiny_llama_q4", "tiny_phi_q8", "tiny_gemma_q8", "tiny_gemma_q4"]
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -134,7 +134,8 @@ def test_golden_fixture_forward(L, golden_dir, name):
     logits_gold = np.load(os.path.join(golden_dir, name + ".logits.npy"))
     m = L.Transformer(img); orc = O.Oracle(img)
     assert m.bytes_consumed == orc.bytes_consumed == img.size
-    cfg_seed = {"tiny_llama_q8": ("tiny-llama", 7), "tiny_llama_q4": ("tiny-llama", 7), "tiny_phi_q8": ("tiny-phi", 9)}[name]
+    cfg_seed = {"tiny_llama_q8": ("tiny-llama", 7), "tiny_llama_q4": ("tiny-llama", 7), "tiny_phi_q8": ("tiny-phi", 9),
+                "tiny_gemma_q8": ("tiny-gemma", 8), "tiny_gemma_q4": ("tiny-gemma", 8)}[name]
     prompt = S.prompt_tokens(*cfg_seed[:1], 5, cfg_seed[1])
     seq = list(prompt) + list(toks_gold[:-1])
     lg = None
@@ -164,15 +165,17 @@ def test_mini_models_logits_bit_exact(L, cfg):
         assert kv == orc.args.n_kv_heads * orc.args.head_size
 
 
-def test_mini_q4_logits_bit_exact(L):
-    img = S.build_image("mini-llama", S.Q4_0, seed=12)
+@pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q4_0), ("mini-gemma", S.Q4_0), ("mini-gemma", S.Q8_0)])
+def test_mini_q4_and_gemma_logits_bit_exact(L, cfg, q):
+    """Q4_0 weights/activations and the Gemma variant (GELU, four norms, soft-caps, head 256): BASELINE configs[2] shapes."""
+    img = S.build_image(cfg, q, seed=12)
     m = L.Transformer(img); orc = O.Oracle(img)
-    prompt = S.prompt_tokens("mini-llama", 4, 12)
+    prompt = S.prompt_tokens(cfg, 4, 12)
     tok = None
     for pos in range(12):
         t = int(prompt[pos]) if pos < len(prompt) else tok
         lo = orc.forward(t, pos)
-        assert_bit_equal(m.forward(t, pos), lo, f"q4 logits at pos {pos}")
+        assert_bit_equal(m.forward(t, pos), lo, f"{cfg} q{q} logits at pos {pos}")
         tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
@@ -207,6 +210,50 @@ def test_llama_1b_q8_greedy_token_ids(L):
     lg = m.forward(int(ref[-1]), 16 + 127)
     assert_bit_equal(lg, orc.forward(int(ref[-1]), 16 + 127), "1B logits at pos 143")
     print(f"\n1B greedy 143 steps: {sec*1e3:.1f} ms on device = {143/sec:.0f} tok/s")
+
+
+def test_gemma_2b_q4_greedy_token_ids(L):
+    """BASELINE.json configs[2]: Gemma-2-2B Q4_0 at full size, greedy token ids identical to the CPU path."""
+    cfg = "gemma-2-2b"
+    img = S.build_image(cfg, S.Q4_0, seed=77)
+    prompt = S.prompt_tokens(cfg, 8, 77)
+    m = L.Transformer(img)
+    got, sec = m.generate_greedy(prompt, 24, timing=True)
+    ref = O.Oracle(img).generate_greedy(prompt, 24)
+    assert (got == ref).all(), f"first mismatch at {int(np.flatnonzero(got != ref)[0])}"
+    print(f"\ngemma-2-2b q4_0: {31/sec:.0f} tok/s")
+
+
+# ------------------------------------------------------------------ row sharding (SURVEY.md §8e)
+@pytest.mark.parametrize("cfg,world", [("mini-llama", 2), ("mini-llama", 8), ("mini-llama3b", 4), ("mini-phi", 8)])
+def test_row_sharding_is_bit_identical(L, cfg, world):
+    """`world` logical shards on ONE device (same kernels, same partition as the multi-GPU path, copies instead of
+    RCCL): every logit must equal the unsharded CPU path bit for bit."""
+    img = S.build_image(cfg, S.Q8_0, seed=31)
+    grp = L.ShardGroup(img, world)
+    orc = O.Oracle(img)
+    prompt = S.prompt_tokens(cfg, 4, 31)
+    tok = None
+    for pos in range(10):
+        t = int(prompt[pos]) if pos < len(prompt) else tok
+        lg, nxt = grp.forward(t, pos)
+        lo = orc.forward(t, pos)
+        assert_bit_equal(lg, lo, f"{cfg} world={world} logits at pos {pos}")
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+        assert nxt == tok
+    grp.close()
+
+
+def test_rccl_path_with_one_rank(L):
+    """The RCCL code path (communicator, all-gathers between the segments, graph capture) with world = 1."""
+    img = S.build_image("mini-llama", S.Q8_0, seed=32)
+    m = L.Transformer(img, rank=0, world=1, unique_id=L.comm_unique_id())
+    orc = O.Oracle(img)
+    prompt = S.prompt_tokens("mini-llama", 4, 32)
+    assert (m.generate_greedy(prompt, 8) == orc.generate_greedy(prompt, 8)).all()
+    o2 = O.Oracle(img)
+    for pos, t in enumerate(prompt):
+        assert_bit_equal(m.forward(int(t), pos), o2.forward(int(t), pos), f"rccl world=1 logits at pos {pos}")
 
 
 # ------------------------------------------------------------------ error behaviour (reference: panics)

@@ -38,6 +38,44 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def exchange_unique_id(dist, rank, make_id):
+    """Rank 0 makes the 128-byte communicator id, every rank receives it (any torch.distributed backend)."""
+    box = [make_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    uid = box[0]
+    assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
+    return bytes(uid)
+
+
+def pmc_traffic(n_gemv_per_step):
+    """HBM bytes per GEMV launch from the committed rocprofv3 PMC passes of this same command (profiles/r1_traffic.json,
+    made by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md applied).
+    bench.py cannot collect hardware counters itself, so this is null when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        k = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    per_step = 0
+    for name, v in k.items():
+        if "gemv" in name:
+            # per step: 16 launches of each layer GEMV, 1 classifier launch; weight each kernel by its share of launches
+            per_step += v["hbm_bytes_per_launch"] * v["launches"]
+    n = sum(v["launches"] for name, v in k.items() if "gemv" in name)
+    return round(per_step / n) if n else None
+
+
+def max_over_ranks(dist, seconds, device=None):
+    """The contract's timing rule: the step time of the job is the slowest rank's."""
+    if dist is None:
+        return seconds
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,8 +121,13 @@ def main():
     prompt = S.prompt_tokens(cfg, W, 1234)
     t_build = time.time() - t0
 
-    # N > 1: this round has no row-sharded path yet -> N independent replicas of the same decode stream.
-    model = lmrs_amd.Transformer(img, device=local_rank)
+    # N > 1: ONE decode stream, weight matrices row-split over the N GPUs (one process per GPU), RCCL all-gathers
+    # of the per-shard slices over xGMI between the fused kernels.  Token ids stay identical.
+    if world > 1:
+        uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
+        model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
+    else:
+        model = lmrs_amd.Transformer(img, device=local_rank)
 
     # ---- warm-up: the W prompt tokens (token by token, as the reference feeds prompts), untimed
     first = model.generate_greedy(prompt, 1)
@@ -94,38 +137,39 @@ def main():
     toks, dev_sec = model.generate_greedy(first, K, start_pos=W, timing=True)
     device_sync(); barrier()
     t2 = time.perf_counter()
-    elapsed = t2 - t1
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(dist, t2 - t1, "cuda" if dist is not None else None)
     gen = np.concatenate([first, toks])[: K + 1]          # token ids produced after positions W-1 .. W+K-1
 
     out = None
     if rank == 0:
-        tok_s = world * K / elapsed
+        tok_s = K / elapsed                      # one decode stream, whatever the number of GPUs
         # whole-path bytes over the timed positions
         path_bytes = sum(model.step_info(p)[1] for p in range(W, W + K))
         n_launch = model.step_info(W)[0]
         # ---- dominant kernel: per-shape live timing with HIP events
-        iters = 5
-        res = model.bench_gemv(iters)
-        per, tot_us, tot_b, n_gemv = {}, 0.0, 0.0, 0
-        for name, (us, b, n) in res.items():
+        path = {"bytes_per_step": round(path_bytes / K), "us_per_step": round(elapsed / K * 1e6, 2),
+                "achieved": round(path_bytes / elapsed / 1e9, 1), "frac": round(path_bytes / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                "kernel_launches_per_step": n_launch, "device_event_us_per_step": round(dev_sec / K * 1e6, 2)}
+        if world > 1:
+            roofline = {"bound": "hbm", "kernel": "whole step (per-kernel timing hook is single-GPU only)", "achieved": path["achieved"],
+                        "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": path["frac"], "traffic": None, "path": path,
+                        "sharded_step_is_one_hipgraph": model.shard_uses_graph()}
+        else:
+          iters = 5
+          res = model.bench_gemv(iters)
+          per, tot_us, tot_b, n_gemv = {}, 0.0, 0.0, 0
+          for name, (us, b, n) in res.items():
             per[name] = {"us": round(us / n, 3), "MB": round(b / n / 1e6, 3), "GBps": round(b / us / 1e3, 1), "launches_per_step": n // iters}
             tot_us += us / iters; tot_b += b / iters; n_gemv += n // iters
-        achieved = tot_b / tot_us / 1e3            # GB/s
-        roofline = {
-            "bound": "hbm", "kernel": "lmrs::gemv_kernel (fused Q8_0 dequant-GEMV, all shapes of one step)",
+          achieved = tot_b / tot_us / 1e3            # GB/s
+          roofline = {
+            "bound": "hbm", "kernel": "lmrs::gemv_static_kernel (fused Q8_0 dequant-GEMV, all shapes of one step)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(n_gemv),
             "bytes_per_launch_avg": round(tot_b / n_gemv), "avg_launch_us": round(tot_us / n_gemv, 3), "launches_per_step": n_gemv,
             "per_shape": per,
-            "path": {"bytes_per_step": round(path_bytes / K), "us_per_step": round(elapsed / K * 1e6, 2),
-                     "achieved": round(path_bytes / elapsed / 1e9, 1), "frac": round(path_bytes / elapsed / 1e9 / HBM_PEAK_GBPS, 4),
-                     "kernel_launches_per_step": n_launch, "device_event_us_per_step": round(dev_sec / K * 1e6, 2)},
-        }
+            "path": path,
+          }
         # ---- CPU baseline + parity gate
         cpu = None; parity = None
         cpu_steps = K if args.cpu_steps < 0 else args.cpu_steps
@@ -143,10 +187,10 @@ def main():
         out = {
             "metric": "decode tok/s + %HBM-roofline, Llama-3.2-1B Q8_0 @1/2/4/8 MI355X vs CPU ref",
             "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine", "data": "synthetic",
             "config": {"workload": f"{cfg.name} Q8_0 (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
-                       "parallelism": "single GPU" if world == 1 else f"{world} independent replicas (row-sharded path not built yet)",
+                       "parallelism": "single GPU" if world == 1 else f"tp{world}: rows of every weight matrix split over {world} GPUs, RCCL all-gather of the slices",
                        "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }

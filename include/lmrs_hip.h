@@ -64,6 +64,12 @@ int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, i
 /* Writes the 128-byte ncclUniqueId for lmrs_create_sharded (call on rank 0). */
 int lmrs_comm_unique_id(void* out128);
 
+/* Host-only: the row ranges shard `rank` of `world` owns.  plan[0..9] = q-head first,count; kv-head first,count;
+ * wo/w2 row first,count; gate/up pair first,count; classifier row first,count. */
+int lmrs_shard_plan(const lmrs_args* args, int rank, int world, int* plan10);
+/* 1: the sharded step is one captured hipGraph (RCCL inside); 0: enqueued call by call; -1: not an RCCL shard. */
+int lmrs_shard_uses_graph(const lmrs_ctx* ctx);
+
 /* Verification aid (no reference counterpart): `world` row shards of one model as `world` contexts on ONE device,
  * exchanged by device-to-device copies instead of RCCL, so the sharding can be checked bit for bit on a 1-GPU box. */
 int lmrs_group_create(const uint8_t* file, size_t len, int device, int world, lmrs_ctx** shards, size_t* bytes_consumed);

@@ -28,7 +28,7 @@ EXPORTS = [
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
     "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline",
-    "lmrs_group_create", "lmrs_group_forward",
+    "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
 ]
 
 
@@ -81,6 +81,8 @@ def lib():
         L.lmrs_bench_gemv.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.lmrs_step_info.argtypes = [vp, u32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.lmrs_debug_timeline.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+        L.lmrs_shard_plan.argtypes = [C.POINTER(TransformerArgs), C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.lmrs_shard_uses_graph.argtypes = [vp]
         L.lmrs_group_create.argtypes = [vp, sz, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
         L.lmrs_group_forward.argtypes = [C.POINTER(vp), C.c_int, u32, u32, C.POINTER(f32p), C.POINTER(u32)]
         _lib = L
@@ -158,6 +160,9 @@ class Transformer:
         _chk(lib().lmrs_generate_greedy(self._h, _p(pr), pr.size, n_new, start_pos, _p(out), C.byref(sec)))
         return (out, sec.value) if timing else out
 
+    def shard_uses_graph(self) -> int:
+        return lib().lmrs_shard_uses_graph(self._h)
+
     # ---- measurement hooks
     def bench_gemv(self, iters: int = 5):
         """-> {shape: (sum_us, sum_bytes, launches)} over `iters` GEMV-only passes of one decode step."""
@@ -176,6 +181,14 @@ class Transformer:
         n, b = C.c_int(), C.c_double()
         _chk(lib().lmrs_step_info(self._h, pos, C.byref(n), C.byref(b)))
         return n.value, b.value
+
+
+def shard_plan(args: TransformerArgs, rank: int, world: int) -> dict:
+    """Row ranges (first, count) shard `rank` of `world` owns; host-only."""
+    p = (C.c_int * 10)()
+    _chk(lib().lmrs_shard_plan(C.byref(args), rank, world, p))
+    k = ["q_heads", "kv_heads", "dim_rows", "hidden_pairs", "vocab_rows"]
+    return {k[i]: (p[2 * i], p[2 * i + 1]) for i in range(5)}
 
 
 def comm_unique_id() -> bytes:

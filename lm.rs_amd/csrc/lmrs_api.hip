@@ -355,6 +355,22 @@ extern "C" int lmrs_comm_unique_id(void* out128) {
 static int create_impl(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid, bool group_mode,
                        lmrs_ctx** out, size_t* bytes_consumed);
 
+// Host-only: the row ranges shard `rank` of `world` owns.  plan[0..9] = q-head first/count, kv-head first/count,
+// wo/w2 row first/count, gate-up pair first/count, classifier row first/count.  <0 if `world` does not divide the model.
+extern "C" int lmrs_shard_plan(const lmrs_args* a, int rank, int world, int* plan) {
+    if (!a || !plan || world < 1 || rank < 0 || rank >= world) return fail("bad argument");
+    if (a->n_kv_heads % world || a->dim % world || a->hidden_dim % world || a->vocab_size % world)
+        return fail("world must divide n_kv_heads, dim, hidden_dim and vocab_size");
+    const int nh = a->n_heads / world, nkv = a->n_kv_heads / world, dl = a->dim / world, hl = a->hidden_dim / world, vl = a->vocab_size / world;
+    const int p[10] = {rank * nh, nh, rank * nkv, nkv, rank * dl, dl, rank * hl, hl, rank * vl, vl};
+    memcpy(plan, p, sizeof p);
+    return 0;
+}
+
+// 1 if the sharded step of this context runs as one captured hipGraph (RCCL collectives inside), 0 if it is enqueued
+// call by call, -1 if the context is not an RCCL shard.
+extern "C" int lmrs_shard_uses_graph(const lmrs_ctx* c) { return !c || !c->comm ? -1 : (c->g_step ? 1 : 0); }
+
 extern "C" int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid,
                                    lmrs_ctx** out, size_t* bytes_consumed) {
     if (world < 1 || rank < 0 || rank >= world) return fail("bad rank/world");
@@ -708,7 +724,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
 // ------------------------------------------------------------------ measurement hooks
 // The GEMV launches of one decode step, in step order (per layer qkv, wo, w1w3, w2; then the classifier),
 // so that the weight stream is the real one (1.27 GB for Llama-3.2-1B: nothing is re-served by the 256 MiB
-// Infinity Cache), each launch bracketed by HIP events on the context's stream.
+// Infinity Cache), each launch carrying its own start/stop HIP events (hipExtLaunchKernelGGL) on the context's stream.
 extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* bytes5, int* count5) {
     if (!c || iters <= 0 || !us5 || !bytes5 || !count5) return fail("bad argument");
     if (c->world > 1 || c->comm) return fail("lmrs_bench_gemv: single-GPU contexts only");
@@ -740,9 +756,10 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
         for (int l = 0; l <= nl; ++l)
             for (int which = (l < nl ? 0 : 4); which < (l < nl ? 4 : 5); ++which) {
                 GemvArgs g; int pro, epi; mk(which, l < nl ? l : 0, g, pro, epi);
-                HIP_OK(hipEventRecord(ev[2 * i], c->stream));
-                HIP_OK(launch_gemv(g, pro, epi, c->stream));
-                HIP_OK(hipEventRecord(ev[2 * i + 1], c->stream));
+                set_gemv_launch_events(ev[2 * i], ev[2 * i + 1]);       // events ride on the dispatch itself
+                const hipError_t le = launch_gemv(g, pro, epi, c->stream);
+                set_gemv_launch_events(nullptr, nullptr);
+                HIP_OK(le);
                 ++i;
             }
         HIP_OK(hipStreamSynchronize(c->stream));

@@ -67,6 +67,7 @@ struct ArgmaxArgs {
 
 // launches (all asynchronous on `s`)
 hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint = 0);
+void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop);   // measurement: attach events to the next GEMV dispatches (null: off)
 int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);

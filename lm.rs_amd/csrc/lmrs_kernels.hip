@@ -27,6 +27,8 @@
 //   - the activation prologue (RMSNorm / quantise) is recomputed by every workgroup from the
 //     L2-resident f32 vector: it runs while the workgroup's first weight loads are in flight and
 //     saves a dependent kernel boundary (~1.2-1.9 us on this chip) per use.
+#include <hip/hip_ext.h>
+
 #include "lmrs_device_math.h"
 #include "lmrs_kernels.h"
 #include "lmrs_stage.h"
@@ -551,6 +553,16 @@ static int static_L(const GemvArgs& a, int pro, int epi) {
     return 0;
 }
 
+// Measurement: when set, the next GEMV launch carries these events on its own dispatch (hipExtLaunchKernelGGL), so
+// that hipEventElapsedTime(start, stop) is that kernel's begin->end time, the same interval rocprofv3 reports.
+static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
+void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop) { t_ev_start = start; t_ev_stop = stop; }
+#define LMRS_LAUNCH(kern, grid, smem, s, a)                                                                 \
+    do {                                                                                                    \
+        if (t_ev_start) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, s, t_ev_start, t_ev_stop, 0, a); \
+        else hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), smem, s, a);                                \
+    } while (0)
+
 static size_t gemv_smem(const GemvArgs& a, int pro) {
     const int n = a.n, G = n / kGS;
     size_t s = ((n + 15) & ~15) + (size_t)((G + 3) & ~3) * 4;
@@ -642,7 +654,7 @@ hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int g
     if (const int sl = static_L(a, pro, epi)) {
 #define X(n_, l_, p_, e_)                                                                                  \
         if (a.n == n_ && sl == l_ && pro == p_ && epi == e_) {                                             \
-            hipLaunchKernelGGL((gemv_static_kernel<n_, l_, p_, e_>), dim3(grid), dim3(kBlock), smem, s, a); \
+            LMRS_LAUNCH((gemv_static_kernel<n_, l_, p_, e_>), grid, smem, s, a);                             \
             return hipGetLastError();                                                                      \
         }
         LMRS_STATIC_TABLE(X)
@@ -651,7 +663,7 @@ hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int g
     const GemvShape sh = resolve_shape(a, pro, epi);
 #define X(l, u, np, p, e, q)                                                                               \
     if (sh.L == l && sh.U == u && sh.NP == np && pro == p && epi == e && (a.q4 != 0) == q) {              \
-        hipLaunchKernelGGL((gemv_kernel<l, u, np, p, e, q>), dim3(grid), dim3(kBlock), smem, s, a);        \
+        LMRS_LAUNCH((gemv_kernel<l, u, np, p, e, q>), grid, smem, s, a);                                   \
         return hipGetLastError();                                                                          \
     }
     LMRS_GEMV_TABLE(X)

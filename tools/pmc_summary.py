@@ -1,0 +1,41 @@
+"""rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes  ->  profiles/<tag>_traffic.json  (HBM traffic per kernel launch).
+
+Collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: separate --pmc passes (FETCH_SIZE takes 3 of the 4 TCC slots),
+--kernel-trace only.  Units: the counters are in KiB.  gfx950 correction: FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced streaming read (16 B/lane), which is what these kernels do, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is taken as is.
+
+usage: python tools/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/r1_traffic.json
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def agg(path, counter):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            d[re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in d.items()}
+
+
+def main(fetch_csv, write_csv, out):
+    f, w = agg(fetch_csv, "FETCH_SIZE"), agg(write_csv, "WRITE_SIZE")
+    res = {}
+    for k, (fv, n) in f.items():
+        wv = w.get(k, (0.0, 0))[0]
+        res[k] = {"launches": n, "FETCH_SIZE_KiB_avg": round(fv, 1), "WRITE_SIZE_KiB_avg": round(wv, 1),
+                  "hbm_bytes_per_launch": round((2 * fv + wv) * 1024)}
+    gemv = {k: v for k, v in res.items() if "gemv" in k}
+    # one decode step of Llama-3.2-1B launches, per layer, one of each of the four layer GEMVs, and one classifier GEMV
+    doc = {"note": __doc__.split("usage")[0].strip(), "kernels": res,
+           "gemv_bytes_weighted_by_launch_count": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemv.values()) / max(1, sum(v["launches"] for v in gemv.values())))}
+    json.dump(doc, open(out, "w"), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print(f"{k[:60]:60s} n={v['launches']:5d}  {v['hbm_bytes_per_launch'] / 1e6:9.3f} MB/launch")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

@@ -81,6 +81,8 @@ struct lmrs_ctx {
     ncclComm_t comm = nullptr;                     // RCCL communicator (one process per GPU); null in group mode
     bool eager = false;                            // sharded step could not be captured: enqueue it every call
     float* part = nullptr;                         // [world][values(cls_grid) | indices(cls_grid)] argmax partials
+    // ---- fused attention block (qkv -> attention -> wo in one launch, in-launch arrival counters)
+    int fused_cls = 0; unsigned* flags = nullptr; int n_flag_words = 0; int* err = nullptr; int* h_err = nullptr;
 
     template <class T> T* alloc(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -137,6 +139,16 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     const bool gemma = a.model_type == LMRS_GEMMA;
     GemvArgs g{};
     g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = gemma; g.st = c->st;
+    g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
+    if (c->fused_cls) {
+        // 1-3 in one launch: qkv -> RoPE + attention -> wo, separated by in-launch arrival counters (lmrs_fused.inc)
+        FusedAttnArgs f{};
+        f.wqkv = static_cast<const int8_t*>(L.wqkv); f.wo = static_cast<const int8_t*>(L.wo); f.sqkv = L.sqkv; f.so = L.so; f.rms_att = L.rms_att;
+        f.eps = a.rms_norm_eps; f.x = c->x; f.q = c->q; f.k_raw = c->k_raw; f.att_out = c->att_out; f.k_cache = c->k_cache; f.v_cache = c->v_cache;
+        f.rope = c->rope; f.seq_len = a.seq_len; f.layer = l; f.flags = c->flags + (size_t)l * kFusedFlagWordsPerLayer; f.err = c->err; f.st = c->st;
+        f.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+        HIP_OK(launch_fused_attn(c->fused_cls, f, a.head_size, c->stream));
+    } else {
     // 1. rmsnorm + quantize | Wqkv | q, raw k, v -> cache            (:409-431)
     g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
     g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
@@ -155,6 +167,7 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
     if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
+    }
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
     g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -201,7 +214,7 @@ int enqueue_step(lmrs_ctx* c) {
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
     ArgmaxArgs m{};
-    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c);
+    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.flags = c->flags; m.n_flag_words = c->n_flag_words;
     m.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
@@ -338,6 +351,18 @@ int upload_interleaved(lmrs_ctx* c, void* dst, const uint8_t* src, size_t row_by
 int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end) {
     c->h_st->pos = (int)pos; c->h_st->prompt_end = (int)prompt_end; c->h_st->step_count = 0; c->h_st->_pad = 0;
     HIP_OK(hipMemcpyAsync(c->st, c->h_st, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+    if (c->flags) {       // in-launch arrival counters and error word start every call from zero
+        HIP_OK(hipMemsetAsync(c->flags, 0, (size_t)c->n_flag_words * 4, c->stream));
+        HIP_OK(hipMemsetAsync(c->err, 0, 4, c->stream));
+    }
+    return 0;
+}
+
+// after a host sync: did a bounded in-launch wait give up?
+int check_err(lmrs_ctx* c) {
+    if (!c->err) return 0;
+    HIP_OK(hipMemcpy(c->h_err, c->err, 4, hipMemcpyDeviceToHost));
+    if (*c->h_err) return fail("in-launch synchronisation timed out at stage " + std::to_string(*c->h_err - 1) + " (results of this call are invalid)");
     return 0;
 }
 
@@ -504,7 +529,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     need(dim * 4); need(att_l * 4); need(kv_l * 4); need(att * 4); need(hid * 4); need(V * 4); need(dim * 4);
     need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4); need(W * 2 * kMaxArgmaxParts * 4);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
-    c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8);
+    c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8); need(nl * kFusedFlagWordsPerLayer * 4 + 512);
     total += 4096;
     HCK(hipMalloc(reinterpret_cast<void**>(&c->arena), total));
     c->arena_bytes = total;
@@ -572,6 +597,19 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     c->part = c->alloc<float>(W * 2 * kMaxArgmaxParts);
     c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
     if (getenv("LMRS_DEBUG_TIMELINE")) { c->dbg = c->alloc<unsigned long long>(8 * 1024); if (c->dbg) HCK(hipMemsetAsync(c->dbg, 0, 8 * 1024 * 8, c->stream)); }
+    // Opt-in (LMRS_FUSED=1): measured on MI355X the in-launch arrive/wait edges cost as much as the two kernel boundaries
+    // they replace (15.6 us fused vs 14.9 us as three launches per layer), so the separate launches stay the default.
+    if (!sharded && getenv("LMRS_FUSED")) {
+        const int cls = fused_attn_class((int)dim, (int)a.n_heads, (int)a.n_kv_heads, (int)a.head_size, c->q4, a.model_type != LMRS_GEMMA);
+        int per_cu = 0; hipDeviceProp_t prop;
+        if (cls && fused_attn_prepare(cls, (int)a.head_size, (int)a.seq_len, &per_cu) == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+            per_cu * prop.multiProcessorCount >= fused_attn_grid(cls)) {      // every workgroup must be resident (they wait on each other)
+            c->n_flag_words = (int)nl * kFusedFlagWordsPerLayer;
+            c->flags = c->alloc<unsigned>(c->n_flag_words); c->err = c->alloc<int>(1);
+            if (c->flags && c->err) c->fused_cls = cls;
+        }
+        (void)hipGetLastError();
+    }
     c->stage = c->alloc<float>(c->stage_floats);
     if (!c->stage) { fail("arena overflow"); return cleanup(); }
     HCK(hipMemsetAsync(c->k_cache, 0, kvn * 4, c->stream)); HCK(hipMemsetAsync(c->v_cache, 0, kvn * 4, c->stream));   // :302-303
@@ -588,6 +626,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_logits), V * 4, hipHostMallocDefault));
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_tok), ((size_t)a.seq_len + 8) * 4, hipHostMallocDefault));
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_st), sizeof(DevState), hipHostMallocDefault));
+    HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_err), 4, hipHostMallocDefault));
     CK(set_state(c, 0, 0));
     HCK(hipStreamSynchronize(c->stream));
     {
@@ -618,6 +657,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->h_logits) hipHostFree(c->h_logits);
     if (c->h_tok) hipHostFree(c->h_tok);
     if (c->h_st) hipHostFree(c->h_st);
+    if (c->h_err) hipHostFree(c->h_err);
     if (c->arena) hipFree(c->arena);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -651,6 +691,7 @@ extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** l
     if (c->world > 1) NCCL_OK(ncclAllGather(c->logits + c->v0, c->logits, (size_t)c->voc_l, ncclFloat, c->comm, c->stream));
     HIP_OK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->args.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    if (check_err(c)) return -1;
     if (logits) *logits = c->h_logits;
     return 0;
 }
@@ -659,6 +700,7 @@ extern "C" int lmrs_forward_argmax(lmrs_ctx* c, uint32_t token, uint32_t pos, ui
     if (step_once(c, token, pos)) return -1;
     HIP_OK(hipMemcpyAsync(c->h_tok + 1, c->tokens + pos + 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    if (check_err(c)) return -1;
     if (next) *next = c->h_tok[1];
     return 0;
 }
@@ -695,6 +737,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
         HIP_OK(hipMemcpyAsync(embeddings + (size_t)i * dim, c->x, dim * 4, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_OK(hipStreamSynchronize(c->stream));
+    if (check_err(c)) return -1;
     if (new_pos) *new_pos = curr_pos + n;
     return 0;
 }
@@ -716,6 +759,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     HIP_OK(hipEventRecord(c->ev1, c->stream));
     if (n_new) HIP_OK(hipMemcpyAsync(c->h_tok, c->tokens + start_pos + n_prompt, (size_t)n_new * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
+    if (check_err(c)) return -1;
     if (n_new) memcpy(out_tokens, c->h_tok, (size_t)n_new * 4);
     if (seconds) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *seconds = ms * 1e-3; }
     return 0;
@@ -782,7 +826,7 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
 extern "C" int lmrs_debug_timeline(lmrs_ctx* c, unsigned long long* out, int max_nodes, int* n_nodes) {
     if (!c || !c->dbg) return fail("debug timeline not enabled (set LMRS_DEBUG_TIMELINE=1 before lmrs_create)");
     HIP_OK(hipSetDevice(c->device));
-    const int n = 5 * (int)c->args.n_layers + 2;
+    const int n = (c->fused_cls ? 3 : 5) * (int)c->args.n_layers + 2;
     const int m = n < max_nodes ? n : max_nodes;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(out, c->dbg, (size_t)m * 8 * 8, hipMemcpyDeviceToHost));
@@ -799,7 +843,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA ? 7 : 5) * (int)a.n_layers + 2;
+    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA ? 7 : (c->fused_cls ? 3 : 5)) * (int)a.n_layers + 2;
     return 0;
 }
 

@@ -62,6 +62,7 @@ struct ArgmaxArgs {
     const float* logits;
     uint32_t* tokens; DevState* st;
     EmbedArgs emb;           // the winner's (or the next prompt token's) embedding row is written to emb.x
+    unsigned* flags; int n_flag_words;   // in-launch arrival counters of the fused kernels: re-zeroed here, at the end of the step
     unsigned long long* dbg;
 };
 
@@ -83,5 +84,19 @@ hipError_t launch_softmax(float* x, int n, hipStream_t st);
 hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st);
 
 constexpr int kMaxArgmaxParts = 4096;
+
+// ---- fused attention block (lmrs_fused.inc): qkv -> attention -> wo of one layer in one launch
+struct FusedAttnArgs {
+    const int8_t *wqkv, *wo; const float *sqkv, *so, *rms_att; float eps;
+    float *x, *q, *k_raw, *att_out; float *k_cache, *v_cache; const float* rope; int seq_len, layer;
+    unsigned* flags;         // this layer's two arrival-counter sets (zeroed at the end of every step)
+    int* err;                // set to stage+1 if a bounded in-launch wait ever times out
+    const DevState* st; unsigned long long* dbg;
+};
+constexpr int kFusedFlagWordsPerLayer = 2 * 8 * 16;
+int fused_attn_class(int dim, int n_heads, int n_kv_heads, int head_size, int q4, int llama_like);
+int fused_attn_grid(int cls);
+hipError_t fused_attn_prepare(int cls, int head_size, int seq_len, int* max_blocks_per_cu);
+hipError_t launch_fused_attn(int cls, const FusedAttnArgs& a, int head_size, hipStream_t s);
 
 }  // namespace lmrs

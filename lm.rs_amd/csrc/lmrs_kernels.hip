@@ -671,30 +671,30 @@ hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int g
     return hipErrorInvalidValue;
 }
 
-constexpr int kAttF4 = 16;           // float4 per lane per chunk: CH * HS / 4 / 256 <= 16
+constexpr int kAttF4 = 16;           // float4 per lane per chunk in the stand-alone kernel: CH * HS / 4 / 256 <= 16
 
 // rows t0 .. t0+ct of one kv head (row stride kv_dim floats) -> registers, 16 B per lane per load, coalesced per row
-template <int HS>
-__device__ __forceinline__ void att_gload(float4 (&rg)[kAttF4], const float* __restrict__ base, int t0, int T, int CH, int kv_dim) {
+template <int HS, int NF>
+__device__ __forceinline__ void att_gload(float4 (&rg)[NF], const float* __restrict__ base, int t0, int T, int CH, int kv_dim) {
     constexpr int HS4 = HS / 4;
     const int ct = (T - t0) < CH ? (T - t0) : CH, nf = ct * HS4;
 #pragma unroll
-    for (int i = 0; i < kAttF4; ++i) {
+    for (int i = 0; i < NF; ++i) {
         const int f = (int)threadIdx.x + i * kBlock;
         const int row = f / HS4, c4 = f - row * HS4;
-        rg[i] = f < nf ? *reinterpret_cast<const float4*>(base + (size_t)(t0 + row) * kv_dim + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rg[i] = f < nf ? ld_f32x4<false>(base + (size_t)(t0 + row) * kv_dim + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 // registers -> LDS tile (row stride HS + 4 floats); optionally scaled per row (V phase: products a_t * v_t[d])
-template <int HS, bool SCALE>
-__device__ __forceinline__ void att_tstore(const float4 (&rg)[kAttF4], float* tile, const float* rowscale, int t0, int T, int CH, int skip_t) {
+template <int HS, int NF, bool SCALE>
+__device__ __forceinline__ void att_tstore(const float4 (&rg)[NF], float* tile, const float* rowscale, int t0, int T, int CH, int skip_t) {
     constexpr int HS4 = HS / 4, RS = HS + 4;
     const int ct = (T - t0) < CH ? (T - t0) : CH;
     // V phase: also write rows ct .. ceil16(ct)-1 (registers hold zeros there and the zero-padded weights scale
     // them by +0.0), so that the serial chain can run in full batches of 16
     const int nf = (SCALE ? ((ct + 15) & ~15) : ct) * HS4;
 #pragma unroll
-    for (int i = 0; i < kAttF4; ++i) {
+    for (int i = 0; i < NF; ++i) {
         const int f = (int)threadIdx.x + i * kBlock;
         const int row = f / HS4, c4 = f - row * HS4;
         if (f < nf && t0 + row != skip_t) {
@@ -712,56 +712,56 @@ __device__ __forceinline__ void att_tstore(const float4 (&rg)[kAttF4], float* ti
 // stays one serial chain of ADDS on one lane; everything order-free runs in parallel: the scores across
 // t, max, exp, divide, the HS output dims, and the products a_t * v_t[d] (formed by all 256 lanes when the
 // V tile is written to LDS, so the serial part is add-only).
-// K and V rows are staged through LDS in chunks of CH timesteps (CH*HS = 16384 floats); all lanes issue
-// their global loads up front (K and V of the first chunk together, before RoPE); the next chunk's loads
-// are in flight while the current one is consumed.
+// K and V rows are staged through LDS in chunks of CH timesteps; all lanes issue their global loads up
+// front (K and V of the first chunk together, before RoPE: the caller does that and hands the registers
+// in); the next chunk's loads are in flight while the current one is consumed.
+// COH: q, the raw key and the V row of this position were produced by other workgroups of the SAME launch
+// (persistent engine) and are read / the output written with agent-scope accesses; the V row of `pos` is
+// then patched in from a coherent read instead of the (possibly stale) prefetched copy.
 // ------------------------------------------------------------------------------------------------
 #define ATT_STAMP(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
 
-template <int HS>
-__global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <int HS, int NF, bool COH>
+__device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, float4 (&kreg)[NF], float4 (&vreg)[NF], uint64_t etab) {
     constexpr int half = HS / 2, HS4 = HS / 4, RS = HS + 4;
-    const int h = blockIdx.x, kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const int kv_dim = a.n_kv_heads * HS;
-    ATT_STAMP(0);
-    const int pos = a.st->pos, T = pos + 1;
+    const int T = pos + 1;
     const int tid = threadIdx.x;
     const int CH = a.chunk;
     float* q = reinterpret_cast<float*>(smem);        // HS
     float* kn = q + HS;                               // HS: rotated key of this position
-    float* red = kn + HS;                             // 16 floats of reduction scratch
-    float* tile = red + 16;                           // CH rows of RS floats (RS = HS + 4: conflict-free float4 row reads)
+    float* vn = kn + HS;                              // HS: value row of this position (COH only)
+    float* red = vn + HS;                             // 16 floats of reduction scratch
+    float* tile = red + 16;                           // CH (+16) rows of RS floats (RS = HS + 4: conflict-free float4 row reads)
     float* att = tile + (size_t)(CH + 16) * RS;       // T (+32 floats of zero padding)
     const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
     const int nchunks = (T + CH - 1) / CH;
-
-    const uint64_t etab = exp2f_tab_lane();
-    float4 kreg[kAttF4], vreg[kAttF4];
     const float* kbase = a.k_cache + loff + kvh * HS;
     const float* vbase = a.v_cache + loff + kvh * HS;
-    att_gload<HS>(kreg, kbase, 0, T, CH, kv_dim);   // row `pos` of K is not in the cache yet (patched from kn below); its load is harmless
-    att_gload<HS>(vreg, vbase, 0, T, CH, kv_dim);   // row `pos` of V was stored by the QKV kernel
-    ATT_STAMP(1);
 
     // RoPE (transformer.rs:480-491) with the host-built (fcr, fci) table
     for (int j = tid; j < half; j += kBlock) {
         const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
         const float fcr = cs.x, fci = cs.y;
         {
-            const float v0 = a.q[h * HS + j], v1 = a.q[h * HS + j + half];
+            const float v0 = ld_f32<COH>(a.q + h * HS + j), v1 = ld_f32<COH>(a.q + h * HS + j + half);
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
             q[j] = a0 - a1; q[j + half] = b0 + b1;
         }
         {
-            const float v0 = a.k_raw[kvh * HS + j], v1 = a.k_raw[kvh * HS + j + half];
+            const float v0 = ld_f32<COH>(a.k_raw + kvh * HS + j), v1 = ld_f32<COH>(a.k_raw + kvh * HS + j + half);
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
             const float r0 = a0 - a1, r1 = b0 + b1;
             kn[j] = r0; kn[j + half] = r1;
-            if (h % kv_mul == 0) {                   // one writer per kv head
+            if (h % kv_mul == 0) {                   // one writer per kv head (read back only by later launches)
                 a.k_cache[loff + (size_t)pos * kv_dim + kvh * HS + j] = r0;
                 a.k_cache[loff + (size_t)pos * kv_dim + kvh * HS + j + half] = r1;
             }
+        }
+        if constexpr (COH) {
+            vn[j] = ld_f32<true>(vbase + (size_t)pos * kv_dim + j);
+            vn[j + half] = ld_f32<true>(vbase + (size_t)pos * kv_dim + j + half);
         }
     }
     lds_barrier();
@@ -772,11 +772,11 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     float lmax = __uint_as_float(0xff800000u);
     for (int c = 0; c < nchunks; ++c) {
         const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore<HS, false>(kreg, tile, nullptr, t0, T, CH, pos);
+        att_tstore<HS, NF, false>(kreg, tile, nullptr, t0, T, CH, pos);
         if (pos >= t0 && pos < t0 + ct && tid < HS4)
             *reinterpret_cast<float4*>(tile + (pos - t0) * RS + tid * 4) = *reinterpret_cast<const float4*>(kn + tid * 4);
         lds_barrier();
-        if (c + 1 < nchunks) att_gload<HS>(kreg, kbase, t0 + CH, T, CH, kv_dim);
+        if (c + 1 < nchunks) att_gload<HS, NF>(kreg, kbase, t0 + CH, T, CH, kv_dim);
         if (c == 0) ATT_STAMP(3);
         if (tid < ct) {
             const float4* kr = reinterpret_cast<const float4*>(tile + tid * RS);
@@ -846,9 +846,17 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     float o = 0.0f;
     for (int c = 0; c < nchunks; ++c) {
         const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore<HS, true>(vreg, tile, att + t0, t0, T, CH, -1);
+        att_tstore<HS, NF, true>(vreg, tile, att + t0, t0, T, CH, COH ? pos : -1);
+        if constexpr (COH) {
+            if (pos >= t0 && pos < t0 + ct && tid < HS4) {
+                float4 v = *reinterpret_cast<const float4*>(vn + tid * 4);
+                const float ap = att[pos];
+                v.x = ap * v.x; v.y = ap * v.y; v.z = ap * v.z; v.w = ap * v.w;
+                *reinterpret_cast<float4*>(tile + (pos - t0) * RS + tid * 4) = v;
+            }
+        }
         lds_barrier();
-        if (c + 1 < nchunks) att_gload<HS>(vreg, vbase, t0 + CH, T, CH, kv_dim);
+        if (c + 1 < nchunks) att_gload<HS, NF>(vreg, vbase, t0 + CH, T, CH, kv_dim);
         if (c == 0) ATT_STAMP(6);
         if (tid < HS) {
             const float* vc = tile + tid;
@@ -864,8 +872,27 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
         }
         lds_barrier();
     }
-    if (tid < HS) a.out[h * HS + tid] = o;
+    if (tid < HS) st_f32<COH>(a.out + h * HS + tid, o);
     ATT_STAMP(7);
+}
+
+template <int HS>
+__global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int h = blockIdx.x, kvh = h / (a.n_heads / a.n_kv_heads), kv_dim = a.n_kv_heads * HS;
+    ATT_STAMP(0);
+    const int pos = a.st->pos, T = pos + 1;
+    const uint64_t etab = exp2f_tab_lane();
+    float4 kreg[kAttF4], vreg[kAttF4];
+    const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
+    att_gload<HS, kAttF4>(kreg, a.k_cache + loff + kvh * HS, 0, T, a.chunk, kv_dim);   // row `pos` of K is not in the cache yet (patched from kn); its load is harmless
+    att_gload<HS, kAttF4>(vreg, a.v_cache + loff + kvh * HS, 0, T, a.chunk, kv_dim);   // row `pos` of V was stored by the QKV kernel
+    ATT_STAMP(1);
+    attention_body<HS, kAttF4, false>(a, h, pos, smem, kreg, vreg, etab);
+}
+
+static size_t attention_smem(int head_size, int chunk, int seq_len) {
+    return (size_t)(3 * head_size + 16 + (size_t)(chunk + 16) * (head_size + 4) + ((seq_len + 3) & ~3) + 32) * 4;
 }
 
 int attention_chunk(int head_size) {
@@ -889,7 +916,7 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
     AttnArgs a = a0;
     a.chunk = attention_chunk(a.head_size);
     if (a.chunk * (a.head_size / 4) > kAttF4 * kBlock) return hipErrorInvalidValue;
-    const size_t smem = (size_t)(2 * a.head_size + 16 + (size_t)(a.chunk + 16) * (a.head_size + 4) + ((a.seq_len + 3) & ~3) + 32) * 4;
+    const size_t smem = attention_smem(a.head_size, a.chunk, a.seq_len);
     switch (a.head_size) {                                      // head sizes of the supported model families
         case 64: return launch_attention_hs<64>(a, smem, s);    // Llama-3.2-1B, tiny test models
         case 96: return launch_attention_hs<96>(a, smem, s);    // Phi-3.5
@@ -980,6 +1007,7 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
         if (a.emb.do_scale) v = v * a.emb.scale;
         a.emb.x[i] = v;
     }
+    for (int i = threadIdx.x; i < a.n_flag_words; i += kBlock) a.flags[i] = 0u;      // nobody polls between steps
     LMRS_STAMP(3);
     if (a.dbg && threadIdx.x == 0) a.dbg[2] = clock64();
 }
@@ -1111,5 +1139,7 @@ hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(expf_kernel, dim3(1024), dim3(256), 0, st, x, y, n);
     return hipGetLastError();
 }
+
+#include "lmrs_fused.inc"
 
 }  // namespace lmrs

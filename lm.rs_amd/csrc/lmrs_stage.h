@@ -15,6 +15,12 @@
 namespace lmrs {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));     // native vector: what the nontemporal builtin accepts
+
+// Pointers that reach a kernel through a table in device memory (the engine's per-layer weight table) are generic
+// to the compiler, which would then emit flat_load (also counted in lgkmcnt).  Every such access goes through an
+// explicit global-address-space pointer.
+#define LMRS_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ const LMRS_GLOBAL T* as_global(const T* p) { return (const LMRS_GLOBAL T*)p; }
 constexpr int kBlk = 256;
 
 // ------------------------------------------------------------------------------------------------
@@ -38,7 +44,11 @@ template <bool COH> __device__ __forceinline__ float4 ld_f32x4(const float* p) {
         const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
                            __uint_as_float((unsigned)(b >> 32)));
-    } else return *reinterpret_cast<const float4*>(p);
+    } else {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 t = *as_global(reinterpret_cast<const f32x4*>(p));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -168,8 +178,8 @@ template <int N, int L>
 __device__ __forceinline__ void tile_issue(WTile<RowGeom<N, L>::U>& t, const int8_t* __restrict__ wq, const float* __restrict__ ws, int row) {
     using R = RowGeom<N, L>;
     const int lane = threadIdx.x & 63, r = lane % L, g0 = (r / 8) * R::U, rc = r & 7;
-    const i32x4* wrow = reinterpret_cast<const i32x4*>(wq + (size_t)row * N) + g0 * 8 + rc;
-    const float* srow = ws + (size_t)row * R::G + g0;
+    const LMRS_GLOBAL i32x4* wrow = as_global(reinterpret_cast<const i32x4*>(wq + (size_t)row * N)) + g0 * 8 + rc;
+    const LMRS_GLOBAL float* srow = as_global(ws) + (size_t)row * R::G + g0;
 #pragma unroll
     for (int u = 0; u < R::U; ++u) {
         t.w[u] = __builtin_nontemporal_load(wrow + u * 8);

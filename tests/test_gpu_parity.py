@@ -256,6 +256,20 @@ def test_rccl_path_with_one_rank(L):
         assert_bit_equal(m.forward(int(t), pos), o2.forward(int(t), pos), f"rccl world=1 logits at pos {pos}")
 
 
+def test_fused_attention_block_in_launch_sync(L, monkeypatch):
+    """LMRS_FUSED=1: qkv -> attention -> wo of a layer as ONE launch whose phases are separated by in-launch arrival
+    counters and agent-scope (write-through / L1-bypassing) exchanges instead of kernel boundaries.  Must be bit-identical."""
+    monkeypatch.setenv("LMRS_FUSED", "1")
+    img = S.build_image("mini-llama", S.Q8_0, seed=41)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    assert m.step_info(0)[0] == 3 * 2 + 2            # 3 launches per layer instead of 5
+    prompt = S.prompt_tokens("mini-llama", 6, 41)
+    assert (m.generate_greedy(prompt, 40) == orc.generate_greedy(prompt, 40)).all()
+    o2 = O.Oracle(img); m2 = L.Transformer(img)
+    for pos, t in enumerate(prompt):
+        assert_bit_equal(m2.forward(int(t), pos), o2.forward(int(t), pos), f"fused logits at pos {pos}")
+
+
 # ------------------------------------------------------------------ error behaviour (reference: panics)
 def test_errors(L):
     img = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "tiny_llama_q8.lmrs"), np.uint8)

@@ -19,12 +19,15 @@ toks, sec = m.generate_greedy(prompt, npos - 15, timing=True)
 print(f"{(16 + npos - 16) / sec:.0f} tok/s over {npos} steps")
 tl = m.debug_timeline().astype(np.int64)
 names = ["qkv", "attn", "wo", "w13", "w2"]
+if os.environ.get("LMRS_FUSED"):
+    names = ["fusedA", "w13", "w2"]
+NK = len(names)
 t0 = tl[0, 0]
 print("node  name   start  | first WG: pro   pass1  end   | last WG: start pro pass1 end | gap_to_next   (us, 10ns clock)")
-L = (len(tl) - 2) // 5
+L = (len(tl) - 2) // NK
 tot = {}
 for i, r in enumerate(tl):
-    name = names[i % 5] if i < 5 * L else ("cls" if i == 5 * L else "argmax")
+    name = names[i % NK] if i < NK * L else ("cls" if i == NK * L else "argmax")
     f = (r[:4] - r[0]) / 100.0
     l = (r[4:] - r[0]) / 100.0
     end = max(r[3], r[7])
@@ -37,7 +40,7 @@ print("\nmean per kernel type: duration(us)  gap_after(us)  prologue(us)  first-
 for k, v in tot.items():
     a = np.array(v)
     print(f"  {k:7s} n={len(v):3d}  {a[:,0].mean():7.2f} {a[:,1].mean():7.2f} {a[:,2].mean():7.2f} {a[:,3].mean():7.2f}")
-att = tl[1::5][:L]
+att = tl[1::5][:L] if NK == 5 else tl[0::NK][:L]
 d = (att - att[:, :1]) / 100.0
 print("attention block0 stamps (us from start): loads-issued, rope-done, k-in-lds, scores-done, softmax-done, v-in-lds, end")
 print("   ", np.round(d[:, [1, 2, 3, 4, 5, 6, 7]].mean(axis=0), 2))

@@ -794,12 +794,15 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
             default: g = cls_args(c); pro = PRO_RMS_QUANT; epi = EPI_CLS; break;
         }
     };
+    // LMRS_BENCH_HOT_LAYER=k (experiment): every layer GEMV reads layer k's weights, i.e. they are served by the 256 MiB
+    // Infinity Cache instead of HBM - how much faster is a cache-resident weight stream?
+    const int hot = getenv("LMRS_BENCH_HOT_LAYER") ? atoi(getenv("LMRS_BENCH_HOT_LAYER")) : -1;
     if (set_state(c, a.seq_len - 1, 0)) return -1;      // the V row the qkv epilogue scribbles on: the last one
     for (int it = -1; it < iters; ++it) {              // it == -1: untimed warm-up pass
         int i = 0;
         for (int l = 0; l <= nl; ++l)
             for (int which = (l < nl ? 0 : 4); which < (l < nl ? 4 : 5); ++which) {
-                GemvArgs g; int pro, epi; mk(which, l < nl ? l : 0, g, pro, epi);
+                GemvArgs g; int pro, epi; mk(which, l < nl ? (hot >= 0 ? hot : l) : 0, g, pro, epi);
                 set_gemv_launch_events(ev[2 * i], ev[2 * i + 1]);       // events ride on the dispatch itself
                 const hipError_t le = launch_gemv(g, pro, epi, c->stream);
                 set_gemv_launch_events(nullptr, nullptr);

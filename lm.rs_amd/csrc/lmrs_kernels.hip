@@ -431,12 +431,13 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
 // HBM latency with counted vmcnt waits; further passes are double-buffered (tile p+1 in flight while p is
 // consumed).
 // ------------------------------------------------------------------------------------------------
+#define LMRS_STAMP0(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
 template <int N, int L, int PRO, int EPI>
 __global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using R = RowGeom<N, L>;
     using V = VecGeom<N>;
-    LMRS_STAMP(0);
+    LMRS_STAMP0(0);
     int8_t* xq = reinterpret_cast<int8_t*>(smem);
     float* xs = reinterpret_cast<float*>(smem + N);
     float* scratch = xs + ((V::G + 3) & ~3);
@@ -453,6 +454,7 @@ __global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
     uint64_t etab = 0;
     if constexpr (EPI == EPI_SWIGLU) etab = exp2f_tab_lane();
     asm volatile("" ::: "memory");               // keep the activation loads ahead of the weight tile in issue order
+    // (waiting for the activation before issuing the tile was measured: no gain - the prologue, not the stream, is the long pole)
     WTile<R::U> ta, tb;
     int pass = blockIdx.x;                      // grid <= n_pass
     tile_issue<N, L>(ta, wq, a.ws, row_of(pass));
@@ -462,11 +464,11 @@ __global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
             *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
         for (int g = threadIdx.x; g < V::G; g += kBlock) xs[g] = a.xs_in[g];
     } else {
-        if constexpr (PRO == PRO_RMS_QUANT) vec_rmsnorm<N>(v, nw, a.eps, a.add_unit, scratch);
+        if constexpr (PRO == PRO_RMS_QUANT) vec_rmsnorm<N>(v, nw, a.eps, a.add_unit, scratch, blockIdx.x == 0 ? a.dbg : nullptr);
         vec_quantize_q8<N>(v, xq, xs);
     }
     lds_barrier();
-    LMRS_STAMP(1);
+    LMRS_STAMP0(1);
 
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;   // EPI_CLS
     const bool writer = r >= L - 8 && (r & 7) == 0;                        // one lane of the row's last cluster
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
         const int p1 = pass + gridDim.x;
         if (p1 < n_pass) tile_issue<N, L>(tb, wq, a.ws, row_of(p1));
         finish(tile_consume<N, L>(ta, xq, xs), pass);
-        if (pass == (int)blockIdx.x) LMRS_STAMP(2);
+        if (pass == (int)blockIdx.x) LMRS_STAMP0(2);
         if (p1 >= n_pass) break;
         const int p2 = p1 + gridDim.x;
         if (p2 < n_pass) tile_issue<N, L>(ta, wq, a.ws, row_of(p2));
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void gemv_static_kernel(const GemvArgs a) {
         if (p2 >= n_pass) break;
         pass = p2;
     }
-    LMRS_STAMP(3);
+    LMRS_STAMP0(3);
     if constexpr (EPI == EPI_CLS) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {

@@ -75,7 +75,8 @@ __device__ __forceinline__ void vec_load(float4 (&v)[VecGeom<N>::NP], const floa
 // RMSNorm (reference functional.rs:48-78), in place on v[]; nw[] = norm weights of the same elements.
 // scratch: 8 * (N/8 + 4) + 4 floats of LDS.
 template <int N>
-__device__ __forceinline__ void vec_rmsnorm(float4 (&v)[VecGeom<N>::NP], const float4 (&nw)[VecGeom<N>::NP], float eps, int add_unit, float* scratch) {
+__device__ __forceinline__ void vec_rmsnorm(float4 (&v)[VecGeom<N>::NP], const float4 (&nw)[VecGeom<N>::NP], float eps, int add_unit, float* scratch,
+                                            unsigned long long* dbg = nullptr) {
     constexpr int NP = VecGeom<N>::NP, JP = N / 8 + 4, NJ4 = N / 32;
     static_assert(N % 256 == 0, "N must be a multiple of 256");
     const int t = threadIdx.x;
@@ -91,27 +92,35 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[VecGeom<N>::NP], const f
         }
     }
     lds_barrier();
+    if (dbg && t == 0) dbg[4] = wall_clock64();          // activation landed, squares in LDS
     if (t < 64) {
         // lanes 0..7: the 8 strided partial sums (ss_sim += x*x), each a serial chain of N/8 adds; the LDS
         // reads run 4 x 16 B ahead of the chain (ping-pong batches).
         float p = 0.0f;
         if (t < 8) {
             const float4* row = reinterpret_cast<const float4*>(scratch + t * JP);
-            float4 A[4], B[4];
+            // The adds are one serial chain; the LDS reads are not.  Two batches of 8 x 16 B ping-pong, with compiler
+            // barriers so that the next batch's reads are ISSUED before the current batch's 32 adds (left alone, the
+            // scheduler sinks the reads next to their uses and exposes the LDS latency once per 16 adds).
+            constexpr int BF = 8;
+            static_assert(NJ4 % (2 * BF) == 0, "row length must be a multiple of 64 floats");
+            float4 A[BF], B[BF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) A[u] = row[u];
+            for (int u = 0; u < BF; ++u) A[u] = row[u];
 #pragma unroll
-            for (int j0 = 0; j0 < NJ4; j0 += 8) {
+            for (int j0 = 0; j0 < NJ4; j0 += 2 * BF) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) B[u] = row[j0 + 4 + u];
+                for (int u = 0; u < BF; ++u) B[u] = row[j0 + BF + u];
+                asm volatile("" : "+v"(p) : : "memory");         // the running sum passes through: the adds below cannot move above the reads
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
-                if (j0 + 8 < NJ4) {
+                for (int u = 0; u < BF; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
+                if (j0 + 2 * BF < NJ4) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) A[u] = row[j0 + 8 + u];
+                    for (int u = 0; u < BF; ++u) A[u] = row[j0 + 2 * BF + u];
                 }
+                asm volatile("" : "+v"(p) : : "memory");
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
+                for (int u = 0; u < BF; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
             }
         }
         const float p0 = __shfl(p, 0), p1 = __shfl(p, 1), p2 = __shfl(p, 2), p3 = __shfl(p, 3);
@@ -125,6 +134,7 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[VecGeom<N>::NP], const f
         }
     }
     lds_barrier();
+    if (dbg && t == 0) dbg[5] = wall_clock64();          // serial chain done
     const float ss = scratch[8 * JP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {

@@ -52,38 +52,40 @@ template <bool COH> __device__ __forceinline__ float4 ld_f32x4(const float* p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Activation vector in registers: thread t owns elements i*1024 + 4t .. +3, i < NP = ceil(N/1024)
+// Activation vector in registers: thread t owns elements i*4*NTH + 4t .. +3, i < NP = ceil(N/(4*NTH))
 // (32 consecutive lanes own one 128-element quantisation group).
 // ------------------------------------------------------------------------------------------------
-template <int N> struct VecGeom {
-    static constexpr int NP = (N + 1023) / 1024;
-    static constexpr bool FULL = (N % 1024) == 0;
+// NTH = threads per workgroup (256 or 512): more threads shorten the per-lane share of the prologue.
+template <int N, int NTH = kBlk> struct VecGeom {
+    static constexpr int PER = NTH * 4;                       // elements per pass over the workgroup
+    static constexpr int NP = (N + PER - 1) / PER;
+    static constexpr bool FULL = (N % PER) == 0;
     static constexpr int G = N / 128;
 };
 
-template <int N, bool COH>
-__device__ __forceinline__ void vec_load(float4 (&v)[VecGeom<N>::NP], const float* __restrict__ x) {
-    constexpr int NP = VecGeom<N>::NP;
+template <int N, bool COH, int NTH = kBlk>
+__device__ __forceinline__ void vec_load(float4 (&v)[(VecGeom<N, NTH>::NP)], const float* __restrict__ x) {
+    constexpr int NP = VecGeom<N, NTH>::NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = i * 1024 + (int)threadIdx.x * 4;
-        if (VecGeom<N>::FULL || i < NP - 1 || e < N) v[i] = ld_f32x4<COH>(x + e);
+        const int e = i * VecGeom<N, NTH>::PER + (int)threadIdx.x * 4;
+        if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) v[i] = ld_f32x4<COH>(x + e);
         else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
 // RMSNorm (reference functional.rs:48-78), in place on v[]; nw[] = norm weights of the same elements.
 // scratch: 8 * (N/8 + 4) + 4 floats of LDS.
-template <int N>
-__device__ __forceinline__ void vec_rmsnorm(float4 (&v)[VecGeom<N>::NP], const float4 (&nw)[VecGeom<N>::NP], float eps, int add_unit, float* scratch,
+template <int N, int NTH = kBlk>
+__device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], const float4 (&nw)[(VecGeom<N, NTH>::NP)], float eps, int add_unit, float* scratch,
                                             unsigned long long* dbg = nullptr) {
-    constexpr int NP = VecGeom<N>::NP, JP = N / 8 + 4, NJ4 = N / 32;
+    constexpr int NP = VecGeom<N, NTH>::NP, JP = N / 8 + 4, NJ4 = N / 32;
     static_assert(N % 256 == 0, "N must be a multiple of 256");
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = i * 1024 + t * 4;
-        if (VecGeom<N>::FULL || i < NP - 1 || e < N) {
+        const int e = i * VecGeom<N, NTH>::PER + t * 4;
+        if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) {
             const int j = e >> 3, k0 = e & 7;
             scratch[(k0 + 0) * JP + j] = v[i].x * v[i].x;
             scratch[(k0 + 1) * JP + j] = v[i].y * v[i].y;
@@ -151,22 +153,33 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[VecGeom<N>::NP], const f
 }
 
 // quantize (reference quantization.rs:44-67) of v[] into LDS: xq[N] int8, xs[N/128] f32.
-template <int N>
-__device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[VecGeom<N>::NP], int8_t* xq, float* xs) {
-    constexpr int NP = VecGeom<N>::NP;
+template <int N, int NTH = kBlk>
+__device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NTH>::NP)], int8_t* xq, float* xs, unsigned long long* dbg = nullptr) {
+    constexpr int NP = VecGeom<N, NTH>::NP;
     const int t = threadIdx.x;
+    // three flat phases (all passes' group maxima, then all scales, then all elements) so that the independent
+    // cross-lane reductions / divisions of the passes overlap instead of running one pass after the other
+    float m[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = i * 1024 + t * 4;
-        const bool live = VecGeom<N>::FULL || i < NP - 1 || e < N;
-        float m = live ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.0f;
-        m = group32_max(m);
-        if (live) {
-            const float scale = m / 127.0f;
-            const int q0 = quant_q8(v[i].x, scale), q1 = quant_q8(v[i].y, scale);
-            const int q2 = quant_q8(v[i].z, scale), q3 = quant_q8(v[i].w, scale);
+        const int e = i * VecGeom<N, NTH>::PER + t * 4;
+        const bool live = VecGeom<N, NTH>::FULL || i < NP - 1 || e < N;
+        m[i] = live ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) m[i] = group32_max(m[i]);        // wmax of each 128-group (max is order-free)
+    if (dbg && t == 0) dbg[6] = wall_clock64();
+    float sc[NP], inv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { sc[i] = m[i] / 127.0f; inv[i] = 1.0f / sc[i]; }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = i * VecGeom<N, NTH>::PER + t * 4;
+        if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) {
+            const int q0 = quant_q8_fast(v[i].x, inv[i], sc[i]), q1 = quant_q8_fast(v[i].y, inv[i], sc[i]);
+            const int q2 = quant_q8_fast(v[i].z, inv[i], sc[i]), q3 = quant_q8_fast(v[i].w, inv[i], sc[i]);
             *reinterpret_cast<unsigned*>(xq + e) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
-            if ((t & 31) == 0) xs[e >> 7] = scale;
+            if ((t & 31) == 0) xs[e >> 7] = sc[i];
         }
     }
 }
@@ -175,9 +188,9 @@ __device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[VecGeom<N>::NP
 // Weight tile: the 16-byte steps one lane holds for one row-pass (Q8_0).
 //   L lanes per row, NC = L/8 clusters, each cluster owns a contiguous segment of U = G/NC groups.
 // ------------------------------------------------------------------------------------------------
-template <int N, int L> struct RowGeom {
+template <int N, int L, int NTH = kBlk> struct RowGeom {
     static constexpr int G = N / 128, NC = L / 8, U = G / NC;
-    static constexpr int RW = 64 / L, RB = RW * (kBlk / 64);      // rows per wave / per workgroup pass
+    static constexpr int RW = 64 / L, RB = RW * (NTH / 64);        // rows per wave / per workgroup pass
     static_assert(G % NC == 0, "row groups must divide over the clusters");
     static_assert(U >= 1 && U <= 24, "a cluster's groups must fit one tile");
 };

@@ -1,0 +1,60 @@
+/*
+ * quant_check.c — TEST INFRASTRUCTURE.  Checks the division-free fast path of the device quantiser
+ * (lm.rs_amd/csrc/lmrs_device_math.h: quant_q8_fast) against the reference arithmetic
+ * q = (x / scale).round() as i8  (reference src/quantization.rs:62-63) on random and adversarial inputs.
+ * The fast path multiplies by 1/scale and falls back to the exact IEEE division whenever the product lies
+ * within 1e-4 of a rounding boundary (k + 0.5), which covers the worst-case error of the product (2.3e-5).
+ *   usage: ./quant_check        (prints the number of mismatches: must be 0)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int exact_q(float x, float scale) {
+    float q = roundf(x / scale);
+    if (q != q) return 0;
+    if (q < -128.0f) q = -128.0f;
+    if (q > 127.0f) q = 127.0f;
+    return (int)q;
+}
+static inline int fast_q(float x, float inv, float scale) {
+    const float r = x * inv;
+    const float n = rintf(r);
+    const float off = fabsf(fabsf(r - n) - 0.5f);
+    if (!(fabsf(r) < 1.0e4f) || off < 1.0e-4f) return exact_q(x, scale);
+    float c = n;
+    if (c < -128.0f) c = -128.0f;
+    if (c > 127.0f) c = 127.0f;
+    return (int)c;
+}
+static uint64_t s = 88172645463325252ull;
+static inline uint32_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 16); }
+static inline float urand(void) { return (float)(rnd() >> 8) / 16777216.0f; }
+
+int main(void) {
+    unsigned long long bad = 0, n = 0;
+    for (long it = 0; it < 400000000L; ++it) {
+        float wmax, x;
+        const uint32_t mode = rnd() & 7;
+        if (mode < 5) { wmax = ldexpf(0.5f + urand(), (int)(rnd() % 40) - 30); x = (2.0f * urand() - 1.0f) * wmax; }
+        else if (mode == 5) { wmax = ldexpf(0.5f + urand(), (int)(rnd() % 250) - 140); x = (2.0f * urand() - 1.0f) * wmax; }   /* huge / denormal scales */
+        else {                                      /* adversarial: x right at a rounding boundary (k + 0.5) * scale, +- a few ulp */
+            wmax = ldexpf(0.5f + urand(), (int)(rnd() % 40) - 30);
+            const float sc = wmax / 127.0f; const int k = (int)(rnd() % 127);
+            x = ((float)k + 0.5f) * sc; uint32_t u; memcpy(&u, &x, 4); u += (rnd() % 9) - 4; memcpy(&x, &u, 4);
+            if (rnd() & 1) x = -x;
+        }
+        const float scale = wmax / 127.0f;
+        const float inv = 1.0f / scale;
+        if (exact_q(x, scale) != fast_q(x, inv, scale)) bad++;
+        n++;
+    }
+    /* degenerate groups */
+    const float zs[] = {0.0f, -0.0f, 1e-45f, 3e-39f, INFINITY, NAN};
+    for (unsigned i = 0; i < sizeof zs / sizeof *zs; ++i)
+        for (unsigned j = 0; j < sizeof zs / sizeof *zs; ++j) { if (exact_q(zs[j], zs[i]) != fast_q(zs[j], 1.0f / zs[i], zs[i])) bad++; n++; }
+    printf("cases: %llu  mismatches: %llu\n", n, bad);
+    return bad != 0;
+}

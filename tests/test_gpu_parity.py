@@ -224,6 +224,20 @@ def test_gemma_2b_q4_greedy_token_ids(L):
     print(f"\ngemma-2-2b q4_0: {31/sec:.0f} tok/s")
 
 
+@pytest.mark.parametrize("cfg,n_steps", [("mini-llama-long", 700), ("mini-phi-long", 400)])
+def test_long_context_multi_chunk_attention(L, cfg, n_steps):
+    """Positions beyond one LDS chunk of K/V rows (256 timesteps at head 64, 160 at head 96): the chunked score and
+    value loops, the serial softmax sum over hundreds of terms.  Token ids over the whole run + bit-equal logits at the end."""
+    img = S.build_image(cfg, S.Q8_0, seed=51)
+    prompt = S.prompt_tokens(cfg, 8, 51)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    got = m.generate_greedy(prompt, n_steps)
+    ref = orc.generate_greedy(prompt, n_steps)
+    assert (got == ref).all(), f"first mismatch at {int(np.flatnonzero(got != ref)[0])}"
+    pos = 8 + n_steps - 1
+    assert_bit_equal(m.forward(int(ref[-1]), pos), orc.forward(int(ref[-1]), pos), f"{cfg} logits at pos {pos}")
+
+
 # ------------------------------------------------------------------ row sharding (SURVEY.md §8e)
 @pytest.mark.parametrize("cfg,world", [("mini-llama", 2), ("mini-llama", 8), ("mini-llama3b", 4), ("mini-phi", 8)])
 def test_row_sharding_is_bit_identical(L, cfg, world):

@@ -61,6 +61,8 @@ CONFIGS = {
     "tiny-phi": ModelCfg("tiny-phi", 128, 256, 2, 4, 96, 4, 256, 64, 1e-5, 10000.0, PHI),
     # mid-size: real head geometry of the 1B model, few layers, small vocab (fast oracle runs)
     "mini-llama": ModelCfg("mini-llama", 2048, 8192, 2, 32, 64, 8, 4096, 256, 1e-5, 500000.0, LLAMA),
+    "mini-llama-long": ModelCfg("mini-llama-long", 2048, 8192, 2, 32, 64, 8, 4096, 2048, 1e-5, 500000.0, LLAMA),
+    "mini-phi-long": ModelCfg("mini-phi-long", 3072, 8192, 2, 32, 96, 32, 4096, 1024, 1e-5, 10000.0, PHI),
     "mini-llama3b": ModelCfg("mini-llama3b", 3072, 8192, 2, 24, 128, 8, 4096, 256, 1e-5, 500000.0, LLAMA),
     "mini-gemma": ModelCfg("mini-gemma", 2304, 9216, 2, 8, 256, 4, 4096, 256, 1e-6, 10000.0, GEMMA),
     "mini-phi": ModelCfg("mini-phi", 3072, 8192, 2, 32, 96, 32, 4096, 256, 1e-5, 10000.0, PHI),

@@ -44,6 +44,10 @@ att = tl[1::5][:L] if NK == 5 else tl[0::NK][:L]
 d = (att - att[:, :1]) / 100.0
 print("attention block0 stamps (us from start): loads-issued, rope-done, k-in-lds, scores-done, softmax-done, v-in-lds, end")
 print("   ", np.round(d[:, [1, 2, 3, 4, 5, 6, 7]].mean(axis=0), 2))
+for nm, off in (("wo", 2), ("w2", 4)):
+    if NK == 5:
+        g = tl[off::5][:L]; d = (g - g[:, :1]) / 100.0
+        print(f"{nm} block0 (us from start): inputs landed+absmax {d[:,6].mean():.2f}  quantised(thread0) {d[:,7].mean():.2f}  barrier {d[:,1].mean():.2f}  rows done {d[:,2].mean():.2f}  end {d[:,3].mean():.2f}")
 for nm, off in (("qkv", 0), ("w13", 3)):
     if NK == 5:
         g = tl[off::5][:L]; d = (g - g[:, :1]) / 100.0

@@ -108,17 +108,21 @@ __device__ __forceinline__ int quant_q8(float x, float scale) {
     return (int)q;
 }
 // Same result without the per-element IEEE division (12 dependent instructions each; the quantiser sits on the
-// critical path of every GEMV prologue): multiply by inv = 1/scale (one division per group) and take the exact path
-// only when the product is within 1e-4 of a rounding boundary k+0.5 - the product can be off by at most 2.3e-5 from
-// the correctly rounded quotient for |q| <= 128 - or is not finite/small.  oracle/quant_check.c: 0 mismatches in 4e8
-// random + adversarial cases.
-__device__ __forceinline__ int quant_q8_fast(float x, float inv, float scale) {
+// critical path of every GEMV prologue).  Branch-free candidate: n = rint(x * inv) with inv = 1/scale (one division
+// per group, or v_rcp_f32: 1 ulp).  The product is at most 3.1e-5 away from the correctly rounded quotient when the group maximum is a
+// normal number in [1e-30, 1e30] (then |x * inv| <= 127.00002, no clamp and no NaN can occur), so the candidate equals
+// round(x / scale) unless the product lies within 1e-4 of a rounding boundary k + 0.5; those lanes - and every lane of
+// a group whose maximum is zero / denormal / huge / NaN - are `quant_slow` and the caller redoes them with quant_q8.
+// oracle/quant_check.c restates this and compares with the reference arithmetic: 0 mismatches in 4e8 random +
+// adversarial cases.
+__device__ __forceinline__ bool quant_group_sane(float wmax) { return wmax > 1.0e-30f && wmax < 1.0e30f; }
+__device__ __forceinline__ int quant_q8_try(float x, float inv, float& dev) {   // dev: running max of |x*inv - rint|
     const float r = x * inv;
     const float n = rintf(r);
-    const float off = fabsf(fabsf(r - n) - 0.5f);
-    if (!(fabsf(r) < 1.0e4f) || off < 1.0e-4f) return quant_q8(x, scale);
-    return (int)fminf(fmaxf(n, -128.0f), 127.0f);
+    dev = __builtin_fmaxf(dev, fabsf(r - n));
+    return (int)n;
 }
+__device__ __forceinline__ bool quant_slow(float wmax, float dev) { return !quant_group_sane(wmax) || dev > 0.4999f; }
 // ((x/scale + 8.0).round() as u8).clamp(0, 15)
 __device__ __forceinline__ unsigned quant_q4(float x, float scale) {
     float q = roundf(x / scale + 8.0f);

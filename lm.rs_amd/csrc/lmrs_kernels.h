@@ -35,6 +35,7 @@ struct GemvArgs {
     float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on (global) rows < softcap_rows
     int row_offset;          // global index of this launch's row 0 (row-sharded classifier)
     unsigned long long* dbg; // optional: 8 wall-clock stamps (debug timeline)
+    int order_barrier;       // set by launch_gemv: workgroup barrier between the activation loads and the weight tile
 };
 
 struct AttnArgs {

@@ -144,9 +144,11 @@ __device__ __forceinline__ void quantize_to_lds(const float4 (&v)[NP], int n, in
             m = group32_max(m);                       // wmax of the 128-group (max is order-free)
             if (live) {
                 if constexpr (!Q4) {
-                    const float scale = m / 127.0f, inv = 1.0f / scale;
-                    const int q0 = quant_q8_fast(v[i].x, inv, scale), q1 = quant_q8_fast(v[i].y, inv, scale);
-                    const int q2 = quant_q8_fast(v[i].z, inv, scale), q3 = quant_q8_fast(v[i].w, inv, scale);
+                    const float scale = m / 127.0f, inv = __builtin_amdgcn_rcpf(scale);
+                    float dev = 0.0f;
+                    int q0 = quant_q8_try(v[i].x, inv, dev), q1 = quant_q8_try(v[i].y, inv, dev);
+                    int q2 = quant_q8_try(v[i].z, inv, dev), q3 = quant_q8_try(v[i].w, inv, dev);
+                    if (quant_slow(m, dev)) { q0 = quant_q8(v[i].x, scale); q1 = quant_q8(v[i].y, scale); q2 = quant_q8(v[i].z, scale); q3 = quant_q8(v[i].w, scale); }
                     const unsigned packed = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
                     *reinterpret_cast<unsigned*>(xq + e) = packed;
                     if ((t & 31) == 0) xs[e >> 7] = scale;
@@ -454,6 +456,9 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     uint64_t etab = 0;
     if constexpr (EPI == EPI_SWIGLU) etab = exp2f_tab_lane();
     asm volatile("" ::: "memory");               // keep the activation loads ahead of the weight tile in issue order
+    // A CU returns vector-memory data in request order across its waves: without this barrier the activation loads of
+    // the workgroup's later waves (L2 hits) queue behind the earlier waves' weight tiles (HBM misses).
+    if (PRO != PRO_PREQ && a.order_barrier) __builtin_amdgcn_s_barrier();
     // (waiting for the activation before issuing the tile was measured: no gain - the prologue, not the stream, is the long pole)
     WTile<R::U> ta, tb;
     int pass = blockIdx.x;                      // grid <= n_pass
@@ -540,12 +545,16 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     X(3072, 32, PRO_RMS_QUANT, EPI_QKV, 256) X(3072, 32, PRO_QUANT, EPI_RESID, 256) X(3072, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256) \
     X(3072, 16, PRO_RMS_QUANT, EPI_CLS, 256) X(3072, 32, PRO_PREQ, EPI_STORE, 256) X(3072, 16, PRO_PREQ, EPI_STORE, 256) \
     /* hidden 8192 */                                                                             \
-    X(8192, 64, PRO_QUANT, EPI_RESID, 512) X(8192, 32, PRO_PREQ, EPI_STORE, 256) X(8192, 32, PRO_QUANT, EPI_RESID, 256)
+    X(8192, 64, PRO_QUANT, EPI_RESID, 512) X(8192, 32, PRO_PREQ, EPI_STORE, 256) X(8192, 32, PRO_QUANT, EPI_RESID, 256)   \
+    X(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 512)
 
 // Workgroup size of a static class.  The w2 projection (n = 8192) has only 2048 rows: at 256 threads that is one wave per
 // SIMD, and its 8192-element quantise prologue - dependent VALU chains - has nothing to interleave with.  512 threads with one
 // row per wave keep the same 256 workgroups and give the prologue twice the lanes (measured 5.5 -> 4.4 us per launch).
+static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int static_NT(const GemvArgs& a, int pro, int epi) {
+    static const int w13_512 = env_flag("LMRS_W13_NT512", 0);
+    if (w13_512 && a.n == 2048 && pro == PRO_RMS_QUANT && epi == EPI_SWIGLU) return 512;
     return (a.n == 8192 && pro == PRO_QUANT && epi == EPI_RESID) ? 512 : 256;
 }
 
@@ -660,7 +669,10 @@ int gemv_grid(const GemvArgs& a, int pro, int epi) {
     return n_pass < cap ? n_pass : cap;
 }
 
-hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint) {
+hipError_t launch_gemv(const GemvArgs& a0, int pro, int epi, hipStream_t s, int grid_hint) {
+    static const int order_barrier = env_flag("LMRS_ORDER_BARRIER", 1);
+    GemvArgs a = a0;
+    a.order_barrier = order_barrier;
     if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
     const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
     const size_t smem = gemv_smem(a, pro);
@@ -1044,8 +1056,28 @@ __global__ __launch_bounds__(kBlock) void quantize_kernel(const float* x, void* 
     quantize_to_lds<Q4, kMaxP>(v, n, xq, xs, q, s);
 }
 
+// The static kernels' quantiser (vec_quantize_q8) behind the same entry point, for the shapes they are built for.
+template <int N, int NTH>
+__global__ __launch_bounds__(NTH) void quantize_static_kernel(const float* x, int8_t* q, float* s) {
+    __shared__ __attribute__((aligned(16))) int8_t xq[N];
+    __shared__ float xs[N / 128];
+    float4 v[(VecGeom<N, NTH>::NP)];
+    vec_load<N, false, NTH>(v, x);
+    vec_quantize_q8<N, NTH>(v, xq, xs);
+    lds_barrier();
+    for (int e = threadIdx.x * 4; e < N; e += NTH * 4) *reinterpret_cast<unsigned*>(q + e) = *reinterpret_cast<const unsigned*>(xq + e);
+    for (int g = threadIdx.x; g < N / 128; g += NTH) s[g] = xs[g];
+}
+
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st) {
     if (n % kGS || n > kMaxP * 1024) return hipErrorInvalidValue;
+    if (!q4 && (n == 2048 || n == 3072 || n == 8192)) {
+        int8_t* q8 = static_cast<int8_t*>(q);
+        if (n == 2048) hipLaunchKernelGGL((quantize_static_kernel<2048, 256>), dim3(1), dim3(256), 0, st, x, q8, s);
+        else if (n == 3072) hipLaunchKernelGGL((quantize_static_kernel<3072, 256>), dim3(1), dim3(256), 0, st, x, q8, s);
+        else hipLaunchKernelGGL((quantize_static_kernel<8192, 512>), dim3(1), dim3(512), 0, st, x, q8, s);
+        return hipGetLastError();
+    }
     const size_t smem = ((n + 15) & ~15) + (size_t)(n / kGS + 4) * 4;
     if (q4) hipLaunchKernelGGL(quantize_kernel<true>, dim3(1), dim3(kBlock), smem, st, x, q, s, n);
     else hipLaunchKernelGGL(quantize_kernel<false>, dim3(1), dim3(kBlock), smem, st, x, q, s, n);

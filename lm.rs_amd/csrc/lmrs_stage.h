@@ -171,14 +171,30 @@ __device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NT
     if (dbg && t == 0) dbg[6] = wall_clock64();
     float sc[NP], inv[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { sc[i] = m[i] / 127.0f; inv[i] = 1.0f / sc[i]; }
+    for (int i = 0; i < NP; ++i) { sc[i] = m[i] / 127.0f; inv[i] = __builtin_amdgcn_rcpf(sc[i]); }   // scale: IEEE division (it is stored); inv: 1 ulp suffices
+    // all candidates first (branch-free, so the passes interleave), then the rare exact redo, one branch per pass
+    int q[NP][4];
+    float dev[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        dev[i] = 0.0f;
+        q[i][0] = quant_q8_try(v[i].x, inv[i], dev[i]); q[i][1] = quant_q8_try(v[i].y, inv[i], dev[i]);
+        q[i][2] = quant_q8_try(v[i].z, inv[i], dev[i]); q[i][3] = quant_q8_try(v[i].w, inv[i], dev[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (quant_slow(m[i], dev[i])) {
+            q[i][0] = quant_q8(v[i].x, sc[i]); q[i][1] = quant_q8(v[i].y, sc[i]);
+            q[i][2] = quant_q8(v[i].z, sc[i]); q[i][3] = quant_q8(v[i].w, sc[i]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int e = i * VecGeom<N, NTH>::PER + t * 4;
         if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) {
-            const int q0 = quant_q8_fast(v[i].x, inv[i], sc[i]), q1 = quant_q8_fast(v[i].y, inv[i], sc[i]);
-            const int q2 = quant_q8_fast(v[i].z, inv[i], sc[i]), q3 = quant_q8_fast(v[i].w, inv[i], sc[i]);
-            *reinterpret_cast<unsigned*>(xq + e) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((unsigned)(q3 & 0xff) << 24);
+            const unsigned lo = __builtin_amdgcn_perm((unsigned)q[i][1], (unsigned)q[i][0], 0x0c0c0400u);
+            const unsigned hi = __builtin_amdgcn_perm((unsigned)q[i][3], (unsigned)q[i][2], 0x0c0c0400u);
+            *reinterpret_cast<unsigned*>(xq + e) = lo | (hi << 16);
             if ((t & 31) == 0) xs[e >> 7] = sc[i];
         }
     }

@@ -1,9 +1,10 @@
 /*
  * quant_check.c — TEST INFRASTRUCTURE.  Checks the division-free fast path of the device quantiser
- * (lm.rs_amd/csrc/lmrs_device_math.h: quant_q8_fast) against the reference arithmetic
+ * (lm.rs_amd/csrc/lmrs_device_math.h: quant_q8_try + quant_group_sane) against the reference arithmetic
  * q = (x / scale).round() as i8  (reference src/quantization.rs:62-63) on random and adversarial inputs.
  * The fast path multiplies by 1/scale and falls back to the exact IEEE division whenever the product lies
- * within 1e-4 of a rounding boundary (k + 0.5), which covers the worst-case error of the product (2.3e-5).
+ * within 1e-4 of a rounding boundary (k + 0.5), which covers the worst-case error of the product (3.1e-5 with a 1-ulp reciprocal), or the
+ * group maximum is not a normal number in [1e-30, 1e30].  |x| <= wmax as in a real group (x is an element of it).
  *   usage: ./quant_check        (prints the number of mismatches: must be 0)
  */
 #include <math.h>
@@ -19,15 +20,14 @@ static inline int exact_q(float x, float scale) {
     if (q > 127.0f) q = 127.0f;
     return (int)q;
 }
-static inline int fast_q(float x, float inv, float scale) {
+/* device form: the candidate (int)rint(x * inv) stands unless the lane raises `slow`; wmax is the group maximum */
+static inline int fast_q(float x, float inv, float scale, float wmax) {
+    int slow = !(wmax > 1.0e-30f && wmax < 1.0e30f);
     const float r = x * inv;
     const float n = rintf(r);
-    const float off = fabsf(fabsf(r - n) - 0.5f);
-    if (!(fabsf(r) < 1.0e4f) || off < 1.0e-4f) return exact_q(x, scale);
-    float c = n;
-    if (c < -128.0f) c = -128.0f;
-    if (c > 127.0f) c = 127.0f;
-    return (int)c;
+    slow |= fabsf(r - n) > 0.4999f;
+    if (slow) return exact_q(x, scale);
+    return (int)n;      /* v_cvt_i32_f32; |n| <= 127 here, asserted below */
 }
 static uint64_t s = 88172645463325252ull;
 static inline uint32_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 16); }
@@ -48,13 +48,16 @@ int main(void) {
         }
         const float scale = wmax / 127.0f;
         const float inv = 1.0f / scale;
-        if (exact_q(x, scale) != fast_q(x, inv, scale)) bad++;
+        if (fabsf(x) > wmax) x = copysignf(wmax, x);
+        /* the device takes inv from v_rcp_f32 (1 ulp): every neighbour of the correctly rounded reciprocal must work */
+        const int e = exact_q(x, scale);
+        if (e != fast_q(x, inv, scale, wmax) || e != fast_q(x, nextafterf(inv, INFINITY), scale, wmax) || e != fast_q(x, nextafterf(inv, 0.0f), scale, wmax)) bad++;
         n++;
     }
     /* degenerate groups */
     const float zs[] = {0.0f, -0.0f, 1e-45f, 3e-39f, INFINITY, NAN};
     for (unsigned i = 0; i < sizeof zs / sizeof *zs; ++i)
-        for (unsigned j = 0; j < sizeof zs / sizeof *zs; ++j) { if (exact_q(zs[j], zs[i]) != fast_q(zs[j], 1.0f / zs[i], zs[i])) bad++; n++; }
+        for (unsigned j = 0; j < sizeof zs / sizeof *zs; ++j) { if (exact_q(zs[j], zs[i] / 127.0f) != fast_q(zs[j], 1.0f / (zs[i] / 127.0f), zs[i] / 127.0f, zs[i])) bad++; n++; }
     printf("cases: %llu  mismatches: %llu\n", n, bad);
     return bad != 0;
 }

@@ -434,7 +434,9 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
 // consumed).
 // ------------------------------------------------------------------------------------------------
 #define LMRS_STAMP0(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
-template <int N, int L, int PRO, int EPI, int NTH>
+// SPLIT > 0: only the first SPLIT steps of the first tile are issued up front, the rest once the activation has landed
+// (caps the bytes every workgroup throws at the memory system in the same instant at kernel start).
+template <int N, int L, int PRO, int EPI, int NTH, int SPLIT = 0>
 __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using R = RowGeom<N, L, NTH>;
@@ -462,15 +464,23 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     // (waiting for the activation before issuing the tile was measured: no gain - the prologue, not the stream, is the long pole)
     WTile<R::U> ta, tb;
     int pass = blockIdx.x;                      // grid <= n_pass
-    tile_issue<N, L>(ta, wq, a.ws, row_of(pass));
+    constexpr int U0 = (SPLIT > 0 && SPLIT < R::U && PRO != PRO_PREQ) ? SPLIT : R::U;
+    const int row0 = row_of(pass);
+    tile_issue<N, L, 0, U0>(ta, wq, a.ws, row0);
+    __builtin_amdgcn_sched_barrier(0);           // the prologue's first wait must not be scheduled above the tile's loads
+    auto rest = [&]() __attribute__((always_inline)) { if constexpr (U0 < R::U) { __builtin_amdgcn_sched_barrier(0); tile_issue<N, L, U0, R::U>(ta, wq, a.ws, row0); } };
 
     if constexpr (PRO == PRO_PREQ) {
         for (int e = threadIdx.x * 16; e < N; e += NTH * 16)
             *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
         for (int g = threadIdx.x; g < V::G; g += NTH) xs[g] = a.xs_in[g];
     } else {
-        if constexpr (PRO == PRO_RMS_QUANT) vec_rmsnorm<N, NTH>(v, nw, a.eps, a.add_unit, scratch, blockIdx.x == 0 ? a.dbg : nullptr);
-        vec_quantize_q8<N, NTH>(v, xq, xs, blockIdx.x == 0 ? a.dbg : nullptr);
+        if constexpr (PRO == PRO_RMS_QUANT) {
+            vec_rmsnorm<N, NTH>(v, nw, a.eps, a.add_unit, scratch, blockIdx.x == 0 ? a.dbg : nullptr, rest);
+            vec_quantize_q8<N, NTH>(v, xq, xs, blockIdx.x == 0 ? a.dbg : nullptr);
+        } else {
+            vec_quantize_q8<N, NTH>(v, xq, xs, blockIdx.x == 0 ? a.dbg : nullptr, rest);
+        }
         if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[7] = wall_clock64();
     }
     lds_barrier();
@@ -546,15 +556,13 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     X(3072, 16, PRO_RMS_QUANT, EPI_CLS, 256) X(3072, 32, PRO_PREQ, EPI_STORE, 256) X(3072, 16, PRO_PREQ, EPI_STORE, 256) \
     /* hidden 8192 */                                                                             \
     X(8192, 64, PRO_QUANT, EPI_RESID, 512) X(8192, 32, PRO_PREQ, EPI_STORE, 256) X(8192, 32, PRO_QUANT, EPI_RESID, 256)   \
-    X(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 512)
+    X(2048, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256) X(2048, 32, PRO_RMS_QUANT, EPI_SWIGLU, 256) X(2048, 16, PRO_RMS_QUANT, EPI_CLS, 256)
 
 // Workgroup size of a static class.  The w2 projection (n = 8192) has only 2048 rows: at 256 threads that is one wave per
 // SIMD, and its 8192-element quantise prologue - dependent VALU chains - has nothing to interleave with.  512 threads with one
 // row per wave keep the same 256 workgroups and give the prologue twice the lanes (measured 5.5 -> 4.4 us per launch).
 static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int static_NT(const GemvArgs& a, int pro, int epi) {
-    static const int w13_512 = env_flag("LMRS_W13_NT512", 0);
-    if (w13_512 && a.n == 2048 && pro == PRO_RMS_QUANT && epi == EPI_SWIGLU) return 512;
     return (a.n == 8192 && pro == PRO_QUANT && epi == EPI_RESID) ? 512 : 256;
 }
 
@@ -562,7 +570,9 @@ static int static_L(const GemvArgs& a, int pro, int epi) {
     if (a.q4 || (epi == EPI_CLS && a.softcap_rows)) return 0;     // static classes: Q8_0, Llama/Phi glue
     // preferred L per (n, o): enough workgroups to cover the chip, rows split over as few clusters as possible
     int want = 0;
-    if (a.n == 2048) want = a.o >= 8192 ? 8 : 32;
+    static const int w13_l = env_flag("LMRS_W13_L", 16);      // w1w3 at dim 2048: 16 lanes per row, two passes per workgroup (measured best of L = 8/16/32 x grid 256/512/1024)
+    static const int cls_l = env_flag("LMRS_CLS_L", 8);
+    if (a.n == 2048) want = a.o >= 8192 ? (epi == EPI_SWIGLU ? w13_l : (epi == EPI_CLS ? cls_l : 8)) : 32;
     else if (a.n == 3072) want = a.o >= 8192 ? 16 : 32;
     else if (a.n == 8192) want = 32;
     if (!want) return 0;
@@ -665,7 +675,10 @@ int gemv_grid(const GemvArgs& a, int pro, int epi) {
     const GemvShape sh = sl ? GemvShape{sl, 0, 0} : resolve_shape(a, pro, epi);
     const int RB = (64 / sh.L) * ((sl ? static_NT(a, pro, epi) : kBlock) / 64);
     const int n_pass = (a.o + RB - 1) / RB;
-    const int cap = (epi == EPI_CLS) ? 512 : 4096;        // classifier: persistent-style grid, prologue paid once per workgroup
+    static const int w13_grid = env_flag("LMRS_W13_GRID", 512), qkv_grid = env_flag("LMRS_QKV_GRID", 4096);
+    int cap = (epi == EPI_CLS) ? 512 : 4096;              // classifier: persistent-style grid, prologue paid once per workgroup
+    if (epi == EPI_SWIGLU) cap = w13_grid;
+    if (epi == EPI_QKV) cap = qkv_grid;
     return n_pass < cap ? n_pass : cap;
 }
 
@@ -678,6 +691,15 @@ hipError_t launch_gemv(const GemvArgs& a0, int pro, int epi, hipStream_t s, int 
     const size_t smem = gemv_smem(a, pro);
     if (const int sl = static_L(a, pro, epi)) {
         const int nt = static_NT(a, pro, epi);
+        static const int split_w13 = env_flag("LMRS_SPLIT_W13", 0), split_w2 = env_flag("LMRS_SPLIT_W2", 0);
+#define XS(n_, l_, p_, e_, nt_, sp_, var_)                                                                  \
+        if (a.n == n_ && sl == l_ && pro == p_ && epi == e_ && nt == nt_ && var_ == sp_) {                  \
+            LMRS_LAUNCH_NT((gemv_static_kernel<n_, l_, p_, e_, nt_, sp_>), grid, nt_, smem, s, a);           \
+            return hipGetLastError();                                                                      \
+        }
+        XS(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 256, 4, split_w13) XS(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 256, 8, split_w13)
+        XS(8192, 64, PRO_QUANT, EPI_RESID, 512, 2, split_w2) XS(8192, 64, PRO_QUANT, EPI_RESID, 512, 4, split_w2)
+#undef XS
 #define X(n_, l_, p_, e_, nt_)                                                                             \
         if (a.n == n_ && sl == l_ && pro == p_ && epi == e_ && nt == nt_) {                                \
             LMRS_LAUNCH_NT((gemv_static_kernel<n_, l_, p_, e_, nt_>), grid, nt_, smem, s, a);                \
@@ -699,34 +721,74 @@ hipError_t launch_gemv(const GemvArgs& a0, int pro, int epi, hipStream_t s, int 
 
 constexpr int kAttF4 = 16;           // float4 per lane per chunk in the stand-alone kernel: CH * HS / 4 / 256 <= 16
 
+// Chunk geometry shared by the loads and the LDS tile writes.  Slot i of a lane is float4 number f = tid + i * 256 of
+// the chunk (row f / HS4, column f % HS4).  Slots are switched on and off in groups of 4 by a wave-uniform test (scalar
+// branch, no exec masking, and the address / predicate arithmetic of the dead slots is skipped with them); rows past
+// the chunk's last one are clamped to it (a harmless duplicate load) instead of being masked off lane by lane.
+// nrows = rows written to the tile = ct rounded up to 16 (the V chain runs in batches of 16).
+template <int HS> struct AttGeom {
+    static constexpr int HS4 = HS / 4, RS = HS + 4;
+    static constexpr bool ALIGNED = (kBlock % HS4 == 0) && ((16 * HS4) % kBlock == 0 || kBlock % (16 * HS4) == 0);   // a slot never straddles nrows
+};
 // rows t0 .. t0+ct of one kv head (row stride kv_dim floats) -> registers, 16 B per lane per load, coalesced per row
 template <int HS, int NF>
 __device__ __forceinline__ void att_gload(float4 (&rg)[NF], const float* __restrict__ base, int t0, int T, int CH, int kv_dim) {
     constexpr int HS4 = HS / 4;
-    const int ct = (T - t0) < CH ? (T - t0) : CH, nf = ct * HS4;
+    const int ct = (T - t0) < CH ? (T - t0) : CH, nrows = (ct + 15) & ~15, nf = nrows * HS4;
+    const int r0 = (int)threadIdx.x / HS4, c4 = (int)threadIdx.x - r0 * HS4;
+    const float* lane_base = base + (size_t)t0 * kv_dim + c4 * 4;
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int f = (int)threadIdx.x + i * kBlock;
-        const int row = f / HS4, c4 = f - row * HS4;
-        rg[i] = f < nf ? ld_f32x4<false>(base + (size_t)(t0 + row) * kv_dim + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0; i0 < NF; i0 += 4) {
+        if (i0 * kBlock < nf) {                                              // wave-uniform
+#pragma unroll
+            for (int i = i0; i < i0 + 4 && i < NF; ++i) {
+                int row;
+                if constexpr (kBlock % HS4 == 0) row = r0 + i * (kBlock / HS4);
+                else row = ((int)threadIdx.x + i * kBlock) / HS4;
+                const int col4 = (kBlock % HS4 == 0) ? 0 : (((int)threadIdx.x + i * kBlock) - row * HS4 - c4) * 4;
+                row = row < ct - 1 ? row : ct - 1;
+                rg[i] = ld_f32x4<false>(lane_base + (size_t)row * kv_dim + col4);
+            }
+        }
     }
 }
-// registers -> LDS tile (row stride HS + 4 floats); optionally scaled per row (V phase: products a_t * v_t[d])
+// registers -> LDS tile (row stride HS + 4 floats); optionally scaled per row (V phase: products a_t * v_t[d]; rows
+// ct .. nrows-1 get the zero-padded weights, i.e. +-0.0 products, so that the serial chain can run in full batches of 16).
+// Row `patch_t` (absolute; -1: none) is then overwritten with patch[] (* its weight) BY THE SAME THREAD that wrote it, so
+// the two LDS writes are ordered without a barrier.
 template <int HS, int NF, bool SCALE>
-__device__ __forceinline__ void att_tstore(const float4 (&rg)[NF], float* tile, const float* rowscale, int t0, int T, int CH, int skip_t) {
+__device__ __forceinline__ void att_tstore(const float4 (&rg)[NF], float* tile, const float* rowscale, int t0, int T, int CH, int patch_t, const float* patch) {
     constexpr int HS4 = HS / 4, RS = HS + 4;
-    const int ct = (T - t0) < CH ? (T - t0) : CH;
-    // V phase: also write rows ct .. ceil16(ct)-1 (registers hold zeros there and the zero-padded weights scale
-    // them by +0.0), so that the serial chain can run in full batches of 16
-    const int nf = (SCALE ? ((ct + 15) & ~15) : ct) * HS4;
+    const int ct = (T - t0) < CH ? (T - t0) : CH, nrows = (ct + 15) & ~15, nf = nrows * HS4;
+    const int r0 = (int)threadIdx.x / HS4, c4 = (int)threadIdx.x - r0 * HS4;
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        const int f = (int)threadIdx.x + i * kBlock;
-        const int row = f / HS4, c4 = f - row * HS4;
-        if (f < nf && t0 + row != skip_t) {
-            float4 v = rg[i];
-            if constexpr (SCALE) { const float a = rowscale[row]; v.x = a * v.x; v.y = a * v.y; v.z = a * v.z; v.w = a * v.w; }
-            *reinterpret_cast<float4*>(tile + row * RS + c4 * 4) = v;
+    for (int i0 = 0; i0 < NF; i0 += 4) {
+        if (i0 * kBlock < nf) {                                              // wave-uniform
+            int row[4], col[4]; float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if constexpr (kBlock % HS4 == 0) { row[u] = r0 + i * (kBlock / HS4); col[u] = c4; }
+                else { const int f = (int)threadIdx.x + i * kBlock; row[u] = f / HS4; col[u] = f - row[u] * HS4; }
+                if constexpr (SCALE) sc[u] = rowscale[row[u] < nrows ? row[u] : nrows - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if (i < NF && (AttGeom<HS>::ALIGNED || row[u] < nrows)) {
+                    float4 v = rg[i];
+                    if constexpr (SCALE) { v.x = sc[u] * v.x; v.y = sc[u] * v.y; v.z = sc[u] * v.z; v.w = sc[u] * v.w; }
+                    *reinterpret_cast<float4*>(tile + row[u] * RS + col[u] * 4) = v;
+                }
+            }
+        }
+    }
+    if (patch_t >= t0 && patch_t < t0 + ct) {                                // wave-uniform
+        const int fb = (patch_t - t0) * HS4, d = ((int)threadIdx.x - fb) & (kBlock - 1);
+        if (d < HS4) {
+            float4 v = *reinterpret_cast<const float4*>(patch + d * 4);
+            if constexpr (SCALE) { const float ap = rowscale[patch_t - t0]; v.x = ap * v.x; v.y = ap * v.y; v.z = ap * v.z; v.w = ap * v.w; }
+            *reinterpret_cast<float4*>(tile + (patch_t - t0) * RS + d * 4) = v;
         }
     }
 }
@@ -798,9 +860,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     float lmax = __uint_as_float(0xff800000u);
     for (int c = 0; c < nchunks; ++c) {
         const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore<HS, NF, false>(kreg, tile, nullptr, t0, T, CH, pos);
-        if (pos >= t0 && pos < t0 + ct && tid < HS4)
-            *reinterpret_cast<float4*>(tile + (pos - t0) * RS + tid * 4) = *reinterpret_cast<const float4*>(kn + tid * 4);
+        att_tstore<HS, NF, false>(kreg, tile, nullptr, t0, T, CH, pos, kn);    // row `pos` comes from the rotated key just computed
         lds_barrier();
         if (c + 1 < nchunks) att_gload<HS, NF>(kreg, kbase, t0 + CH, T, CH, kv_dim);
         if (c == 0) ATT_STAMP(3);
@@ -872,15 +932,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     float o = 0.0f;
     for (int c = 0; c < nchunks; ++c) {
         const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore<HS, NF, true>(vreg, tile, att + t0, t0, T, CH, COH ? pos : -1);
-        if constexpr (COH) {
-            if (pos >= t0 && pos < t0 + ct && tid < HS4) {
-                float4 v = *reinterpret_cast<const float4*>(vn + tid * 4);
-                const float ap = att[pos];
-                v.x = ap * v.x; v.y = ap * v.y; v.z = ap * v.z; v.w = ap * v.w;
-                *reinterpret_cast<float4*>(tile + (pos - t0) * RS + tid * 4) = v;
-            }
-        }
+        att_tstore<HS, NF, true>(vreg, tile, att + t0, t0, T, CH, COH ? pos : -1, vn);
         lds_barrier();
         if (c + 1 < nchunks) att_gload<HS, NF>(vreg, vbase, t0 + CH, T, CH, kv_dim);
         if (c == 0) ATT_STAMP(6);

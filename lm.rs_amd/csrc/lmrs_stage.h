@@ -22,6 +22,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));     // native vector: wha
 #define LMRS_GLOBAL __attribute__((address_space(1)))
 template <class T> __device__ __forceinline__ const LMRS_GLOBAL T* as_global(const T* p) { return (const LMRS_GLOBAL T*)p; }
 constexpr int kBlk = 256;
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // ------------------------------------------------------------------------------------------------
 // Memory flavours.  COH = data exchanged between workgroups INSIDE one launch (persistent engine):
@@ -76,9 +77,10 @@ __device__ __forceinline__ void vec_load(float4 (&v)[(VecGeom<N, NTH>::NP)], con
 
 // RMSNorm (reference functional.rs:48-78), in place on v[]; nw[] = norm weights of the same elements.
 // scratch: 8 * (N/8 + 4) + 4 floats of LDS.
-template <int N, int NTH = kBlk>
+// `landed` runs right after the first barrier, i.e. once the activation has arrived (hook for deferred weight loads).
+template <int N, int NTH = kBlk, class F = NoHook>
 __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], const float4 (&nw)[(VecGeom<N, NTH>::NP)], float eps, int add_unit, float* scratch,
-                                            unsigned long long* dbg = nullptr) {
+                                            unsigned long long* dbg = nullptr, F landed = F()) {
     constexpr int NP = VecGeom<N, NTH>::NP, JP = N / 8 + 4, NJ4 = N / 32;
     static_assert(N % 256 == 0, "N must be a multiple of 256");
     const int t = threadIdx.x;
@@ -94,6 +96,7 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
         }
     }
     lds_barrier();
+    landed();
     if (dbg && t == 0) dbg[4] = wall_clock64();          // activation landed, squares in LDS
     if (t < 64) {
         // lanes 0..7: the 8 strided partial sums (ss_sim += x*x), each a serial chain of N/8 adds; the LDS
@@ -153,8 +156,8 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
 }
 
 // quantize (reference quantization.rs:44-67) of v[] into LDS: xq[N] int8, xs[N/128] f32.
-template <int N, int NTH = kBlk>
-__device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NTH>::NP)], int8_t* xq, float* xs, unsigned long long* dbg = nullptr) {
+template <int N, int NTH = kBlk, class F = NoHook>
+__device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NTH>::NP)], int8_t* xq, float* xs, unsigned long long* dbg = nullptr, F landed = F()) {
     constexpr int NP = VecGeom<N, NTH>::NP;
     const int t = threadIdx.x;
     // three flat phases (all passes' group maxima, then all scales, then all elements) so that the independent
@@ -166,6 +169,7 @@ __device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NT
         const bool live = VecGeom<N, NTH>::FULL || i < NP - 1 || e < N;
         m[i] = live ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.0f;
     }
+    landed();                                                     // the activation has arrived in this wave
 #pragma unroll
     for (int i = 0; i < NP; ++i) m[i] = group32_max(m[i]);        // wmax of each 128-group (max is order-free)
     if (dbg && t == 0) dbg[6] = wall_clock64();
@@ -213,14 +217,15 @@ template <int N, int L, int NTH = kBlk> struct RowGeom {
 
 template <int U> struct WTile { i32x4 w[U]; float sc[U]; };
 
-template <int N, int L>
+// steps [U0, U1) of the tile (the whole tile by default)
+template <int N, int L, int U0 = 0, int U1 = RowGeom<N, L>::U>
 __device__ __forceinline__ void tile_issue(WTile<RowGeom<N, L>::U>& t, const int8_t* __restrict__ wq, const float* __restrict__ ws, int row) {
     using R = RowGeom<N, L>;
     const int lane = threadIdx.x & 63, r = lane % L, g0 = (r / 8) * R::U, rc = r & 7;
     const LMRS_GLOBAL i32x4* wrow = as_global(reinterpret_cast<const i32x4*>(wq + (size_t)row * N)) + g0 * 8 + rc;
     const LMRS_GLOBAL float* srow = as_global(ws) + (size_t)row * R::G + g0;
 #pragma unroll
-    for (int u = 0; u < R::U; ++u) {
+    for (int u = U0; u < U1; ++u) {
         t.w[u] = __builtin_nontemporal_load(wrow + u * 8);
         t.sc[u] = srow[u];
     }

@@ -809,8 +809,14 @@ __device__ __forceinline__ void att_tstore(const float4 (&rg)[NF], float* tile, 
 // ------------------------------------------------------------------------------------------------
 #define ATT_STAMP(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
 
-template <int HS, int NF, bool COH>
-__device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, float4 (&kreg)[NF], float4 (&vreg)[NF], uint64_t etab) {
+// Inputs of the RoPE step that the stand-alone kernel loads itself, ahead of its K/V loads (a CU returns loads in
+// request order: issued after them, these few bytes would only arrive behind the whole first K/V chunk).
+struct AttPre { float q0, q1, k0, k1; float2 cs; };
+
+template <int HS, int NF, bool COH, bool PRE = false>
+__device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, float4 (&kreg)[NF], float4 (&vreg)[NF], uint64_t etab,
+                                               const AttPre& pre = AttPre()) {
+    static_assert(!PRE || HS / 2 <= kBlock, "one RoPE pair per lane");
     constexpr int half = HS / 2, HS4 = HS / 4, RS = HS + 4;
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const int kv_dim = a.n_kv_heads * HS;
@@ -822,7 +828,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     float* vn = kn + HS;                              // HS: value row of this position (COH only)
     float* red = vn + HS;                             // 16 floats of reduction scratch
     float* tile = red + 16;                           // CH (+16) rows of RS floats (RS = HS + 4: conflict-free float4 row reads)
-    float* att = tile + (size_t)(CH + 16) * RS;       // T (+32 floats of zero padding)
+    float* att = tile + (size_t)(CH + 32) * RS;       // T (+32 floats of zero padding, +32 of read-ahead)
     const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
     const int nchunks = (T + CH - 1) / CH;
     const float* kbase = a.k_cache + loff + kvh * HS;
@@ -830,15 +836,16 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
 
     // RoPE (transformer.rs:480-491) with the host-built (fcr, fci) table
     for (int j = tid; j < half; j += kBlock) {
-        const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
+        float2 cs;
+        if constexpr (PRE) cs = pre.cs; else cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
         const float fcr = cs.x, fci = cs.y;
         {
-            const float v0 = ld_f32<COH>(a.q + h * HS + j), v1 = ld_f32<COH>(a.q + h * HS + j + half);
+            const float v0 = PRE ? pre.q0 : ld_f32<COH>(a.q + h * HS + j), v1 = PRE ? pre.q1 : ld_f32<COH>(a.q + h * HS + j + half);
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
             q[j] = a0 - a1; q[j + half] = b0 + b1;
         }
         {
-            const float v0 = ld_f32<COH>(a.k_raw + kvh * HS + j), v1 = ld_f32<COH>(a.k_raw + kvh * HS + j + half);
+            const float v0 = PRE ? pre.k0 : ld_f32<COH>(a.k_raw + kvh * HS + j), v1 = PRE ? pre.k1 : ld_f32<COH>(a.k_raw + kvh * HS + j + half);
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
             const float r0 = a0 - a1, r1 = b0 + b1;
             kn[j] = r0; kn[j + half] = r1;
@@ -896,8 +903,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     }
     ATT_STAMP(4);
     // softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
+    lmax = wave64_max(lmax);
     if ((tid & 63) == 0) red[tid >> 6] = lmax;
     lds_barrier();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -909,16 +915,9 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     if (tid < 32) att[T + tid] = 0.0f;                       // +0.0 padding for the batched serial sum
     lds_barrier();
     if (tid == 0) {
-        // serial sum (functional.rs:134).  Reads are issued 32 ahead of the chain; the ragged tail is padded with
-        // +0.0 (exact: the running sum of exponentials is >= +0), so there is no one-LDS-read-per-add tail loop.
-        float sum = 0.0f;
-        for (int t = 0; t < T; t += 32) {                  // att[T .. T+31] was zero-padded above
-            float4 e[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) e[u] = *reinterpret_cast<const float4*>(att + t + u * 4);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { sum = sum + e[u].x; sum = sum + e[u].y; sum = sum + e[u].z; sum = sum + e[u].w; }
-        }
+        // serial sum (functional.rs:134); the ragged tail is padded with +0.0 (att[T .. T+31] above; exact: the running
+        // sum of exponentials is >= +0), so there is no one-LDS-read-per-add tail loop
+        const float sum = serial_sum16<1>(0.0f, att, T);
         red[4] = sum;
     }
     lds_barrier();
@@ -937,16 +936,9 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
         if (c + 1 < nchunks) att_gload<HS, NF>(vreg, vbase, t0 + CH, T, CH, kv_dim);
         if (c == 0) ATT_STAMP(6);
         if (tid < HS) {
-            const float* vc = tile + tid;
-            // serial chain of adds over t; 16 LDS reads in flight per batch; tail padded with +0.0 (exact: the
-            // accumulator starts at +0.0 and can never become -0.0)
-            for (int t = 0; t < ct; t += 16) {                 // rows ct .. ct+15 of the tile are zero (att_tstore)
-                float pv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) pv[u] = vc[(t + u) * RS];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) o = o + pv[u];
-            }
+            // serial chain of adds over t; rows ct .. ceil16(ct)-1 of the tile hold +-0.0 products (att_tstore), exact
+            // no-ops for an accumulator that starts at +0.0 and therefore can never be -0.0
+            o = serial_sum16<RS, false>(o, tile + tid, ct);
         }
         lds_barrier();
     }
@@ -959,18 +951,24 @@ __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int h = blockIdx.x, kvh = h / (a.n_heads / a.n_kv_heads), kv_dim = a.n_kv_heads * HS;
     ATT_STAMP(0);
-    const int pos = a.st->pos, T = pos + 1;
     const uint64_t etab = exp2f_tab_lane();
     float4 kreg[kAttF4], vreg[kAttF4];
     const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
+    constexpr int half = HS / 2;
+    const int j = threadIdx.x < half ? (int)threadIdx.x : 0;
+    const int pos = a.st->pos, T = pos + 1;                 // first: the K/V loads depend on it
+    AttPre pre;                                             // RoPE inputs ahead of the K/V loads (a CU returns loads in request order)
+    pre.q0 = a.q[h * HS + j]; pre.q1 = a.q[h * HS + j + half];
+    pre.k0 = a.k_raw[kvh * HS + j]; pre.k1 = a.k_raw[kvh * HS + j + half];
+    pre.cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
     att_gload<HS, kAttF4>(kreg, a.k_cache + loff + kvh * HS, 0, T, a.chunk, kv_dim);   // row `pos` of K is not in the cache yet (patched from kn); its load is harmless
     att_gload<HS, kAttF4>(vreg, a.v_cache + loff + kvh * HS, 0, T, a.chunk, kv_dim);   // row `pos` of V was stored by the QKV kernel
     ATT_STAMP(1);
-    attention_body<HS, kAttF4, false>(a, h, pos, smem, kreg, vreg, etab);
+    attention_body<HS, kAttF4, false, true>(a, h, pos, smem, kreg, vreg, etab, pre);
 }
 
 static size_t attention_smem(int head_size, int chunk, int seq_len) {
-    return (size_t)(3 * head_size + 16 + (size_t)(chunk + 16) * (head_size + 4) + ((seq_len + 3) & ~3) + 32) * 4;
+    return (size_t)(3 * head_size + 16 + (size_t)(chunk + 32) * (head_size + 4) + ((seq_len + 3) & ~3) + 64) * 4;   // +16 tile rows / +32 floats: serial_sum16's read-ahead
 }
 
 int attention_chunk(int head_size) {

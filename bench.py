@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="llama-3.2-1b")
+    ap.add_argument("--qtype", default="q8_0", choices=["q8_0", "q4_0"], help="weight quantisation of the synthetic image (config 3: gemma-2-2b q4_0)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1: same as the GPU run, 0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -117,7 +118,8 @@ def main():
     if W + K > 8192:
         raise SystemExit("warmup + steps must fit the 8192-position KV cache")
     t0 = time.time()
-    img = S.build_image(cfg, S.Q8_0, seed=1234)
+    qt = S.Q8_0 if args.qtype == "q8_0" else S.Q4_0
+    img = S.build_image(cfg, qt, seed=1234)
     prompt = S.prompt_tokens(cfg, W, 1234)
     t_build = time.time() - t0
 
@@ -163,7 +165,7 @@ def main():
             tot_us += us / iters; tot_b += b / iters; n_gemv += n // iters
           achieved = tot_b / tot_us / 1e3            # GB/s
           roofline = {
-            "bound": "hbm", "kernel": "lmrs::gemv_static_kernel (fused Q8_0 dequant-GEMV, all shapes of one step)",
+            "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel (fused dequant-GEMV, all shapes of one step)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": pmc_traffic(n_gemv),
             "bytes_per_launch_avg": round(tot_b / n_gemv), "avg_launch_us": round(tot_us / n_gemv, 3), "launches_per_step": n_gemv,
@@ -188,8 +190,8 @@ def main():
             "metric": "decode tok/s + %HBM-roofline, Llama-3.2-1B Q8_0 @1/2/4/8 MI355X vs CPU ref",
             "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
-            "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine", "data": "synthetic",
-            "config": {"workload": f"{cfg.name} Q8_0 (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
+            "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine" if args.qtype == "q8_0" else "int4xint4->int32, f32 combine", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} {args.qtype.upper()} (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
                        "parallelism": "single GPU" if world == 1 else f"tp{world}: rows of every weight matrix split over {world} GPUs, RCCL all-gather of the slices",
                        "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,

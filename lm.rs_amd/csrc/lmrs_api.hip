@@ -69,6 +69,7 @@ struct lmrs_ctx {
     // pinned host
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
+    float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
     bool q4 = false;
@@ -154,7 +155,12 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
     g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_QKV, c->stream));
+    // Gemma, folded form: the residual lives in x at the top of a layer except that, from layer 1 on, the previous
+    // layer's "x += rmsnorm(ffn_out, post_ffn)" (:643-650) is still pending in (x2, tmp): this prologue applies it, x2 -> x.
+    const bool pending = c->gemma_fused && l > 0;
+    if (pending) { g.xin = c->x2; g.delta = c->tmp; g.add_w = c->layers[l - 1].rms_post_ffn; g.xout = c->x; }
+    HIP_OK(launch_gemv(g, pending ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_QKV, c->stream));
+    g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
     // 2. RoPE + attention                                               (:443-544)
     AttnArgs t{};
     t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->att_out;
@@ -166,17 +172,29 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
-    if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
+    if (gemma && !c->gemma_fused) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
     }
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
     g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
+    if (c->gemma_fused) { g.delta = c->tmp; g.add_w = L.rms_post_att; g.xout = c->x2; }      // x2 = x + rmsnorm(wo_out, post_att) (:563-568), then pre_ffn norm
+    HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
+    g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
     // 5. quantize | W2 | x += ...                                       (:630-654)
     g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
-    if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));   // :643-650
+    if (gemma && !c->gemma_fused) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));   // :643-650
+    return 0;
+}
+
+// Folded Gemma form: after the last layer "x2 += rmsnorm(tmp, post_ffn)" is still pending (the classifier's prologue
+// applies it); callers that need the finished residual stream in x (fill_kv_cache) run this instead.
+int enqueue_finish_residual(lmrs_ctx* c) {
+    if (!c->gemma_fused) return 0;
+    const lmrs_args& a = c->args;
+    HIP_OK(launch_addnorm(c->x2, c->tmp, c->layers[a.n_layers - 1].rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));
+    HIP_OK(hipMemcpyAsync(c->x, c->x2, (size_t)a.dim * 4, hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 
@@ -193,6 +211,7 @@ GemvArgs cls_args(lmrs_ctx* c) {
         g.part_idx = reinterpret_cast<int*>(c->part + (size_t)c->rank * 2 * c->cls_grid) + c->cls_grid;
     } else { g.part_val = c->part_val; g.part_idx = c->part_idx; }
     g.softcap_rows = a.model_type == LMRS_GEMMA ? (int)a.dim : 0;
+    if (c->gemma_fused) { g.xin = c->x2; g.delta = c->tmp; g.add_w = c->layers[a.n_layers - 1].rms_post_ffn; g.xout = c->x; }
     return g;
 }
 
@@ -212,7 +231,7 @@ int enqueue_step(lmrs_ctx* c) {
     c->dbg_node = c->dbg_node;   // (nodes numbered in launch order)
     GemvArgs g = cls_args(c);                                   // final rmsnorm + quantize | classifier | argmax partials (:341-381)
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
+    HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
     ArgmaxArgs m{};
     m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.flags = c->flags; m.n_flag_words = c->n_flag_words;
     m.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -326,6 +345,7 @@ int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out) {
     if (full) rc = c->world > 1 || c->comm ? enqueue_step_sharded(c) : enqueue_step(c);
     else {
         for (uint32_t l = 0; l < c->args.n_layers && !rc; ++l) rc = enqueue_layer(c, (int)l);
+        if (!rc) rc = enqueue_finish_residual(c);
         if (!rc) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
     }
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
@@ -348,8 +368,8 @@ int upload_interleaved(lmrs_ctx* c, void* dst, const uint8_t* src, size_t row_by
     return 0;
 }
 
-int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end) {
-    c->h_st->pos = (int)pos; c->h_st->prompt_end = (int)prompt_end; c->h_st->step_count = 0; c->h_st->_pad = 0;
+int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end, int win_base = -1) {
+    c->h_st->pos = (int)pos; c->h_st->prompt_end = (int)prompt_end; c->h_st->step_count = 0; c->h_st->win_base = win_base;
     HIP_OK(hipMemcpyAsync(c->st, c->h_st, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
     if (c->flags) {       // in-launch arrival counters and error word start every call from zero
         HIP_OK(hipMemsetAsync(c->flags, 0, (size_t)c->n_flag_words * 4, c->stream));
@@ -526,7 +546,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     const size_t kvn = nl * a.seq_len * kv_l;
     need(kvn * 4); need(kvn * 4);
     need((size_t)a.seq_len * a.head_size * 4);                               // rope table
-    need(dim * 4); need(att_l * 4); need(kv_l * 4); need(att * 4); need(hid * 4); need(V * 4); need(dim * 4);
+    need(dim * 4); need(att_l * 4); need(kv_l * 4); need(att * 4); need(hid * 4); need(V * 4); need(dim * 4); need(dim * 4);
     need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4); need(W * 2 * kMaxArgmaxParts * 4);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
     c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8); need(nl * kFusedFlagWordsPerLayer * 4 + 512);
@@ -592,7 +612,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     c->k_cache = c->alloc<float>(kvn); c->v_cache = c->alloc<float>(kvn);
     c->rope = c->alloc<float>((size_t)a.seq_len * a.head_size);
     c->x = c->alloc<float>(dim); c->q = c->alloc<float>(att_l); c->k_raw = c->alloc<float>(kv_l); c->att_out = c->alloc<float>(att);
-    c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V); c->tmp = c->alloc<float>(dim);
+    c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V); c->tmp = c->alloc<float>(dim); c->x2 = c->alloc<float>(dim);
     c->part_val = c->alloc<float>(kMaxArgmaxParts); c->part_idx = c->alloc<int>(kMaxArgmaxParts);
     c->part = c->alloc<float>(W * 2 * kMaxArgmaxParts);
     c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
@@ -629,9 +649,18 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_err), 4, hipHostMallocDefault));
     CK(set_state(c, 0, 0));
     HCK(hipStreamSynchronize(c->stream));
+    if (a.model_type == LMRS_GEMMA && !sharded && !getenv("LMRS_GEMMA_UNFUSED")) {
+        // fold the two "x += rmsnorm(branch)" steps of a Gemma layer into the consuming GEMV prologues when every launch of the
+        // step has a static kernel that can do it (otherwise: the separate addnorm launches)
+        GemvArgs q{}; q.q4 = c->q4; q.n = a.dim; q.o = c->att_dim + 2 * c->kv_dim;
+        GemvArgs f = q; f.o = 2 * a.hidden_dim;
+        GemvArgs k = q; k.o = c->voc_l; k.softcap_rows = (int)a.dim;
+        c->gemma_fused = gemv_is_static(q, PRO_ADD_RMS_QUANT, EPI_QKV) && gemv_is_static(f, PRO_ADD_RMS_QUANT, EPI_GELU) &&
+                         gemv_is_static(k, PRO_ADD_RMS_QUANT, EPI_CLS);
+    }
     {
         GemvArgs g = cls_args(c);
-        c->cls_grid = gemv_grid(g, PRO_RMS_QUANT, EPI_CLS);
+        c->cls_grid = gemv_grid(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS);
     }
     if (!sharded) {
         CK(capture(c, true, &c->g_step));
@@ -730,7 +759,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
     // forward_layer(sl = n) for every layer is, value for value, n single-token passes through the
     // layers (causal; each token's arithmetic only sees tokens <= itself), so the decode graph is reused.
     const size_t dim = c->args.dim;
-    if (set_state(c, curr_pos, 0)) return -1;
+    if (set_state(c, curr_pos, 0, (int)curr_pos)) return -1;      // one forward_layer(sl = n) call: Gemma's window test sees curr_pos for every token
     for (uint32_t i = 0; i < n; ++i) {
         HIP_OK(hipMemcpyAsync(c->x, embeddings + (size_t)i * dim, dim * 4, hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipGraphLaunch(c->g_layers, c->stream));
@@ -784,14 +813,19 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
         g = GemvArgs{}; pro = PRO_QUANT; epi = EPI_STORE;
         g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = a.model_type == LMRS_GEMMA; g.st = c->st;
         g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = layer;
+        const bool gemma = a.model_type == LMRS_GEMMA, fz = c->gemma_fused;     // same launches as enqueue_layer / enqueue_step
         switch (which) {
             case 0: g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim; g.xin = c->x; g.rms_w = L.rms_att;
-                    g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache; pro = PRO_RMS_QUANT; epi = EPI_QKV; break;
-            case 1: g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = c->x; epi = EPI_RESID; break;
-            case 2: g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h;
-                    pro = PRO_RMS_QUANT; epi = EPI_SWIGLU; break;
-            case 3: g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = c->x; epi = EPI_RESID; break;
-            default: g = cls_args(c); pro = PRO_RMS_QUANT; epi = EPI_CLS; break;
+                    g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache; pro = PRO_RMS_QUANT; epi = EPI_QKV;
+                    if (fz && layer > 0) { g.xin = c->x2; g.delta = c->tmp; g.add_w = c->layers[layer - 1].rms_post_ffn; g.xout = c->x; pro = PRO_ADD_RMS_QUANT; }
+                    break;
+            case 1: g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x; epi = gemma ? EPI_STORE : EPI_RESID; break;
+            case 2: g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
+                    pro = PRO_RMS_QUANT; epi = gemma ? EPI_GELU : EPI_SWIGLU;
+                    if (fz) { g.delta = c->tmp; g.add_w = L.rms_post_att; g.xout = c->x2; pro = PRO_ADD_RMS_QUANT; }
+                    break;
+            case 3: g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = gemma ? c->tmp : c->x; epi = gemma ? EPI_STORE : EPI_RESID; break;
+            default: g = cls_args(c); pro = fz ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT; epi = EPI_CLS; break;
         }
     };
     // LMRS_BENCH_HOT_LAYER=k (experiment): every layer GEMV reads layer k's weights, i.e. they are served by the 256 MiB
@@ -846,7 +880,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA ? 7 : (c->fused_cls ? 3 : 5)) * (int)a.n_layers + 2;
+    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (c->fused_cls ? 3 : 5)) * (int)a.n_layers + 2;
     return 0;
 }
 

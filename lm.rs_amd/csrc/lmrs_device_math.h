@@ -185,6 +185,16 @@ __device__ __forceinline__ unsigned quant_q4(float x, float scale) {
     return (unsigned)q;
 }
 
+// Q4_0 candidate, same scheme: n = rint(x * inv + 8.0); for a sane group |x * inv| <= 8.000002, the sum differs from the
+// reference's fl(fl(x / scale) + 8.0) by < 3e-6, so n is the reference's result unless the sum lies within 1e-4 of k + 0.5.
+__device__ __forceinline__ unsigned quant_q4_try(float x, float inv, float& dev) {
+    const float s = x * inv + 8.0f;                              // -ffp-contract=off: product rounded, then the sum
+    const float n = rintf(s);
+    dev = __builtin_fmaxf(dev, fabsf(s - n));
+    const unsigned q = (unsigned)(int)n;                         // n >= -0.0
+    return q < 15u ? q : 15u;
+}
+
 // wide 0.7.x f32x8::reduce_add (AVX path): ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)).
 __device__ __forceinline__ float reduce_add8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
     const float q0 = v0 + v4, q1 = v1 + v5, q2 = v2 + v6, q3 = v3 + v7;

@@ -11,10 +11,10 @@ struct DevState {
     int pos;          // position of the token being processed
     int prompt_end;   // absolute position from which the argmax is written back as the next input
     int step_count;   // statistics
-    int _pad;
+    int win_base;     // >= 0: first position of a batched forward_layer call (Gemma window quirk, see attention_body); < 0: decode
 };
 
-enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2 };
+enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3 };   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
 enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5 };
 
 struct GemvArgs {
@@ -26,6 +26,7 @@ struct GemvArgs {
     const float* xin;        // PRO_QUANT / PRO_RMS_QUANT: n f32
     const void* xq_in; const float* xs_in;   // PRO_PREQ: already quantised activation
     const float* rms_w; float eps; int add_unit;   // PRO_RMS_QUANT
+    const float* delta; const float* add_w; float* xout;   // PRO_ADD_RMS_QUANT: x' = xin + rmsnorm(delta, add_w) -> xout (a buffer other than xin)
     // outputs
     float* out;              // STORE: out[o]; RESID: out[i] += ; SWIGLU/GELU: out[o/2]; CLS: logits
     // EPI_QKV
@@ -71,6 +72,7 @@ struct ArgmaxArgs {
 hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint = 0);
 void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop);   // measurement: attach events to the next GEMV dispatches (null: off)
 int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
+bool gemv_is_static(const GemvArgs& a, int pro, int epi); // a compile-time-shape kernel exists for this launch
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_addvec(float* x, const float* d, int n, hipStream_t st);

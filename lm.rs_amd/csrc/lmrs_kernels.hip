@@ -434,12 +434,16 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
 // consumed).
 // ------------------------------------------------------------------------------------------------
 #define LMRS_STAMP0(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
-// SPLIT > 0: only the first SPLIT steps of the first tile are issued up front, the rest once the activation has landed
-// (caps the bytes every workgroup throws at the memory system in the same instant at kernel start).
-template <int N, int L, int PRO, int EPI, int NTH, int SPLIT = 0>
+// Q4: packed-nibble weights and the reference's Q4_0 activation quantiser (lmrs_stage.h).
+// PRO_ADD_RMS_QUANT (Gemma-2, transformer.rs:563-572 / 643-650 + the next norm): x' = x + rmsnorm(delta, add_w) is formed by
+// every workgroup from the previous GEMV's output vector `delta` - that folds the reference's separate
+// "x += rmsnorm(branch output)" step into the prologue of the kernel that consumes x' (one launch less per branch, a
+// second serial norm chain more) - and workgroup 0 stores x' to `xout`, a DIFFERENT buffer from `xin` (the other
+// workgroups are still reading it); the caller ping-pongs the two residual buffers.
+template <int N, int L, int PRO, int EPI, int NTH, bool Q4 = false>
 __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using R = RowGeom<N, L, NTH>;
+    using R = RowGeom<N, L, NTH, Q4>;
     using V = VecGeom<N, NTH>;
     LMRS_STAMP0(0);
     int8_t* xq = reinterpret_cast<int8_t*>(smem);
@@ -448,11 +452,13 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane % L;
     const int o = a.o, n_pass = (o + R::RB - 1) / R::RB;
     const int8_t* wq = reinterpret_cast<const int8_t*>(a.wq);
+    constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT;
 
-    float4 v[V::NP], nw[V::NP];
+    float4 v[V::NP], nw[V::NP], dl[V::NP], aw[V::NP];
     if constexpr (PRO != PRO_PREQ) {
+        if constexpr (PRO == PRO_ADD_RMS_QUANT) { vec_load<N, false, NTH>(dl, a.delta); vec_load<N, false, NTH>(aw, a.add_w); }
         vec_load<N, false, NTH>(v, a.xin);
-        if constexpr (PRO == PRO_RMS_QUANT) vec_load<N, false, NTH>(nw, a.rms_w);
+        if constexpr (HAS_RMS) vec_load<N, false, NTH>(nw, a.rms_w);
     }
     auto row_of = [&](int pass) __attribute__((always_inline)) { const int rw = pass * R::RB + wave * R::RW + lane / L; return rw < o ? rw : o - 1; };
     uint64_t etab = 0;
@@ -461,33 +467,40 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     // A CU returns vector-memory data in request order across its waves: without this barrier the activation loads of
     // the workgroup's later waves (L2 hits) queue behind the earlier waves' weight tiles (HBM misses).
     if (PRO != PRO_PREQ && a.order_barrier) __builtin_amdgcn_s_barrier();
-    // (waiting for the activation before issuing the tile was measured: no gain - the prologue, not the stream, is the long pole)
+    // (waiting for the activation before issuing the tile, or issuing only part of it first, was measured: no gain)
     WTile<R::U> ta, tb;
     int pass = blockIdx.x;                      // grid <= n_pass
-    constexpr int U0 = (SPLIT > 0 && SPLIT < R::U && PRO != PRO_PREQ) ? SPLIT : R::U;
-    const int row0 = row_of(pass);
-    tile_issue<N, L, 0, U0>(ta, wq, a.ws, row0);
+    tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(pass));
+    // (two-pass launches: issuing the second tile here as well was measured - slower on every model: the more bytes the
+    // chip has in flight, the later every workgroup's activation lands)
     __builtin_amdgcn_sched_barrier(0);           // the prologue's first wait must not be scheduled above the tile's loads
-    auto rest = [&]() __attribute__((always_inline)) { if constexpr (U0 < R::U) { __builtin_amdgcn_sched_barrier(0); tile_issue<N, L, U0, R::U>(ta, wq, a.ws, row0); } };
 
     if constexpr (PRO == PRO_PREQ) {
-        for (int e = threadIdx.x * 16; e < N; e += NTH * 16)
+        constexpr int XB = Q4 ? N / 2 : N;
+        for (int e = threadIdx.x * 16; e < XB; e += NTH * 16)
             *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
         for (int g = threadIdx.x; g < V::G; g += NTH) xs[g] = a.xs_in[g];
     } else {
-        if constexpr (PRO == PRO_RMS_QUANT) {
-            vec_rmsnorm<N, NTH>(v, nw, a.eps, a.add_unit, scratch, blockIdx.x == 0 ? a.dbg : nullptr, rest);
-            vec_quantize_q8<N, NTH>(v, xq, xs, blockIdx.x == 0 ? a.dbg : nullptr);
-        } else {
-            vec_quantize_q8<N, NTH>(v, xq, xs, blockIdx.x == 0 ? a.dbg : nullptr, rest);
+        unsigned long long* dbg = blockIdx.x == 0 ? a.dbg : nullptr;
+        if constexpr (PRO == PRO_ADD_RMS_QUANT) {
+            vec_rmsnorm<N, NTH>(dl, aw, a.eps, a.add_unit, scratch);                 // rmsnorm(branch output)
+#pragma unroll
+            for (int i = 0; i < V::NP; ++i) {
+                v[i].x = v[i].x + dl[i].x; v[i].y = v[i].y + dl[i].y; v[i].z = v[i].z + dl[i].z; v[i].w = v[i].w + dl[i].w;   // x[i] += emb[i]
+                const int e = i * V::PER + (int)threadIdx.x * 4;
+                if (blockIdx.x == 0 && (V::FULL || i < V::NP - 1 || e < N)) *reinterpret_cast<float4*>(a.xout + e) = v[i];
+            }
         }
+        if constexpr (HAS_RMS) vec_rmsnorm<N, NTH>(v, nw, a.eps, a.add_unit, scratch, dbg);
+        if constexpr (Q4) vec_quantize_q4<N, NTH>(v, xq, xs, dbg);
+        else vec_quantize_q8<N, NTH>(v, xq, xs, dbg);
         if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[7] = wall_clock64();
     }
     lds_barrier();
     LMRS_STAMP0(1);
 
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;   // EPI_CLS
-    const bool writer = r >= L - 8 && (r & 7) == 0;                        // one lane of the row's last cluster
+    const bool writer = r >= L - R::CL && (r % R::CL) == 0;                // one lane of the row's last cluster
 
     auto finish = [&](float acc, int ps) __attribute__((always_inline)) {
         const int row = ps * R::RB + wave * R::RW + lane / L;
@@ -506,10 +519,19 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
             const float up = __shfl_down(acc, L);                       // rows interleaved: 2i gate, 2i+1 up
             const float hval = swiglu_t(acc, up, etab);                 // all lanes (expf shuffles its table)
             if (valid && writer && ((lane / L) & 1) == 0) a.out[row >> 1] = hval;
+        } else if constexpr (EPI == EPI_GELU) {
+            const float up = __shfl_down(acc, L);
+            if (valid && writer && ((lane / L) & 1) == 0) a.out[row >> 1] = geglu(acc, up);
         } else if constexpr (EPI == EPI_CLS) {
             if (valid && writer) {
-                a.out[row] = acc;
-                if (acc > best) { best = acc; best_i = row + a.row_offset; }
+                float vv = acc;
+                if (row + a.row_offset < a.softcap_rows) {              // Gemma, transformer.rs:375-381 (first `dim` logits only)
+                    vv = vv / 30.0f;
+                    vv = (float)tanh((double)vv);
+                    vv = vv * 30.0f;
+                }
+                a.out[row] = vv;
+                if (vv > best) { best = vv; best_i = row + a.row_offset; }
             }
         }
     };
@@ -517,13 +539,13 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     // double-buffered passes
     for (;;) {
         const int p1 = pass + gridDim.x;
-        if (p1 < n_pass) tile_issue<N, L>(tb, wq, a.ws, row_of(p1));
-        finish(tile_consume<N, L>(ta, xq, xs), pass);
+        if (p1 < n_pass) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));
+        finish(tile_consume<N, L, Q4>(ta, xq, xs), pass);
         if (pass == (int)blockIdx.x) LMRS_STAMP0(2);
         if (p1 >= n_pass) break;
         const int p2 = p1 + gridDim.x;
-        if (p2 < n_pass) tile_issue<N, L>(ta, wq, a.ws, row_of(p2));
-        finish(tile_consume<N, L>(tb, xq, xs), p1);
+        if (p2 < n_pass) tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(p2));
+        finish(tile_consume<N, L, Q4>(tb, xq, xs), p1);
         if (p2 >= n_pass) break;
         pass = p2;
     }
@@ -546,43 +568,54 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     }
 }
 
-// Static classes: (N, L, PRO, EPI).  Q8_0, Llama/Phi glue.  Chosen when (n, pro, epi) matches and o suits L.
-#define LMRS_STATIC_TABLE(X)                                                                      \
-    /* dim 2048: Llama-3.2-1B */                                                                  \
-    X(2048, 32, PRO_RMS_QUANT, EPI_QKV, 256) X(2048, 32, PRO_QUANT, EPI_RESID, 256) X(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 256) \
-    X(2048, 8, PRO_RMS_QUANT, EPI_CLS, 256) X(2048, 32, PRO_PREQ, EPI_STORE, 256) X(2048, 8, PRO_PREQ, EPI_STORE, 256)   \
-    /* dim 3072: Llama-3.2-3B, Phi-3.5 */                                                         \
-    X(3072, 32, PRO_RMS_QUANT, EPI_QKV, 256) X(3072, 32, PRO_QUANT, EPI_RESID, 256) X(3072, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256) \
-    X(3072, 16, PRO_RMS_QUANT, EPI_CLS, 256) X(3072, 32, PRO_PREQ, EPI_STORE, 256) X(3072, 16, PRO_PREQ, EPI_STORE, 256) \
-    /* hidden 8192 */                                                                             \
-    X(8192, 64, PRO_QUANT, EPI_RESID, 512) X(8192, 32, PRO_PREQ, EPI_STORE, 256) X(8192, 32, PRO_QUANT, EPI_RESID, 256)   \
-    X(2048, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256) X(2048, 32, PRO_RMS_QUANT, EPI_SWIGLU, 256) X(2048, 16, PRO_RMS_QUANT, EPI_CLS, 256)
+// Static classes (N, L, PRO, EPI, threads, Q4): the instantiated shapes of the supported model families.
+#define LMRS_STATIC_TABLE(X)                                                                                            \
+    /* Q8_0, dim 2048 / hidden 8192: Llama-3.2-1B */                                                                    \
+    X(2048, 32, PRO_RMS_QUANT, EPI_QKV, 256, false) X(2048, 32, PRO_QUANT, EPI_RESID, 256, false) X(2048, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256, false) \
+    X(2048, 8, PRO_RMS_QUANT, EPI_CLS, 256, false) X(2048, 32, PRO_PREQ, EPI_STORE, 256, false) X(2048, 8, PRO_PREQ, EPI_STORE, 256, false) \
+    X(8192, 64, PRO_QUANT, EPI_RESID, 512, false) X(8192, 32, PRO_PREQ, EPI_STORE, 256, false)                          \
+    /* Q8_0, dim 3072: Llama-3.2-3B, Phi-3.5 */                                                                         \
+    X(3072, 32, PRO_RMS_QUANT, EPI_QKV, 256, false) X(3072, 16, PRO_RMS_QUANT, EPI_QKV, 256, false) X(3072, 32, PRO_QUANT, EPI_RESID, 256, false) \
+    X(3072, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256, false) X(3072, 16, PRO_RMS_QUANT, EPI_CLS, 256, false)                  \
+    X(3072, 32, PRO_PREQ, EPI_STORE, 256, false) X(3072, 16, PRO_PREQ, EPI_STORE, 256, false)                           \
+    /* Q8_0, Gemma-2-2B: dim 2304, att 2048, hidden 9216 */                                                             \
+    X(2304, 16, PRO_RMS_QUANT, EPI_QKV, 256, false) X(2304, 16, PRO_ADD_RMS_QUANT, EPI_QKV, 256, false) X(2048, 32, PRO_QUANT, EPI_STORE, 256, false) \
+    X(2304, 16, PRO_ADD_RMS_QUANT, EPI_GELU, 256, false) X(9216, 64, PRO_QUANT, EPI_STORE, 512, false) X(2304, 8, PRO_ADD_RMS_QUANT, EPI_CLS, 256, false) \
+    /* Q4_0, Gemma-2-2B */                                                                                              \
+    X(2304, 8, PRO_RMS_QUANT, EPI_QKV, 256, true) X(2304, 8, PRO_ADD_RMS_QUANT, EPI_QKV, 256, true) X(2048, 32, PRO_QUANT, EPI_STORE, 256, true) \
+    X(2304, 8, PRO_ADD_RMS_QUANT, EPI_GELU, 256, true) X(9216, 32, PRO_QUANT, EPI_STORE, 512, true) X(2304, 8, PRO_ADD_RMS_QUANT, EPI_CLS, 256, true) \
+    /* Q4_0, Llama-3.2-1B */                                                                                            \
+    X(2048, 16, PRO_RMS_QUANT, EPI_QKV, 256, true) X(2048, 32, PRO_QUANT, EPI_RESID, 256, true) X(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 256, true) \
+    X(8192, 32, PRO_QUANT, EPI_RESID, 512, true) X(2048, 8, PRO_RMS_QUANT, EPI_CLS, 256, true)
 
-// Workgroup size of a static class.  The w2 projection (n = 8192) has only 2048 rows: at 256 threads that is one wave per
-// SIMD, and its 8192-element quantise prologue - dependent VALU chains - has nothing to interleave with.  512 threads with one
-// row per wave keep the same 256 workgroups and give the prologue twice the lanes (measured 5.5 -> 4.4 us per launch).
 static int env_flag(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int static_NT(const GemvArgs& a, int pro, int epi) {
-    return (a.n == 8192 && pro == PRO_QUANT && epi == EPI_RESID) ? 512 : 256;
-}
 
-static int static_L(const GemvArgs& a, int pro, int epi) {
-    if (a.q4 || (epi == EPI_CLS && a.softcap_rows)) return 0;     // static classes: Q8_0, Llama/Phi glue
-    // preferred L per (n, o): enough workgroups to cover the chip, rows split over as few clusters as possible
-    int want = 0;
-    static const int w13_l = env_flag("LMRS_W13_L", 16);      // w1w3 at dim 2048: 16 lanes per row, two passes per workgroup (measured best of L = 8/16/32 x grid 256/512/1024)
-    static const int cls_l = env_flag("LMRS_CLS_L", 8);
-    if (a.n == 2048) want = a.o >= 8192 ? (epi == EPI_SWIGLU ? w13_l : (epi == EPI_CLS ? cls_l : 8)) : 32;
-    else if (a.n == 3072) want = a.o >= 8192 ? 16 : 32;
-    else if (a.n == 8192) want = 32;
-    if (!want) return 0;
-    const int nt = static_NT(a, pro, epi);
-    if (a.n == 8192 && nt == 512) want = 64;                                  // one row per wave
-#define X(n_, l_, p_, e_, nt_) if (a.n == n_ && want == l_ && pro == p_ && epi == e_ && nt == nt_) return l_;
+// The class (L, threads) for a launch, or L = 0 when the shape has no static kernel (the generic kernel takes it).
+//   * L: enough workgroups to cover the chip with rows split over as few clusters as possible; w1w3 at 16 lanes per row and
+//     two passes per workgroup (measured best of L = 8/16/32 x grid 256/512/1024 at dim 2048).
+//   * threads: the w2 projection has few rows and a long quantise prologue (8192 / 9216 elements of dependent VALU chains):
+//     512 threads keep the workgroup count and give the prologue twice the lanes (measured 5.5 -> 4.4 us per launch).
+struct StaticClass { int L, nt; };
+static StaticClass static_class(const GemvArgs& a, int pro, int epi) {
+    const bool q4 = a.q4 != 0, glu = epi == EPI_SWIGLU || epi == EPI_GELU;
+    int L = 0, nt = 256;
+    if (!q4) {
+        if (a.n == 2048) L = glu ? 16 : (a.o >= 8192 ? 8 : 32);
+        else if (a.n == 3072) L = a.o >= 8192 ? 16 : 32;
+        else if (a.n == 2304) L = epi == EPI_CLS ? 8 : 16;
+        else if (a.n == 8192) { if (pro == PRO_QUANT) { L = 64; nt = 512; } else L = 32; }
+        else if (a.n == 9216) { L = 64; nt = 512; }
+    } else {
+        if (a.n == 2304) L = 8;
+        else if (a.n == 2048) L = epi == EPI_QKV ? 16 : (a.o >= 8192 ? 8 : 32);
+        else if (a.n == 9216 || a.n == 8192) { L = 32; nt = 512; }
+    }
+#define X(n_, l_, p_, e_, nt_, q_) if (a.n == n_ && L == l_ && pro == p_ && epi == e_ && nt == nt_ && q4 == q_) return {L, nt};
     LMRS_STATIC_TABLE(X)
 #undef X
-    return 0;
+    return {0, 256};
 }
+bool gemv_is_static(const GemvArgs& a, int pro, int epi) { return static_class(a, pro, epi).L != 0; }
 
 // Measurement: when set, the next GEMV launch carries these events on its own dispatch (hipExtLaunchKernelGGL), so
 // that hipEventElapsedTime(start, stop) is that kernel's begin->end time, the same interval rocprofv3 reports.
@@ -598,7 +631,7 @@ void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop) { t_ev_start = st
 static size_t gemv_smem(const GemvArgs& a, int pro) {
     const int n = a.n, G = n / kGS;
     size_t s = ((n + 15) & ~15) + (size_t)((G + 3) & ~3) * 4;
-    if (pro == PRO_RMS_QUANT) s += (size_t)(8 * (n / 8 + 4) + 4) * 4;
+    if (pro == PRO_RMS_QUANT || pro == PRO_ADD_RMS_QUANT) s += (size_t)(8 * (n / 8 + 4) + 4) * 4;
     return s < 64 ? 64 : s;
 }
 
@@ -671,14 +704,13 @@ static GemvShape resolve_shape(const GemvArgs& a, int pro, int epi) {
 }
 
 int gemv_grid(const GemvArgs& a, int pro, int epi) {
-    const int sl = static_L(a, pro, epi);
-    const GemvShape sh = sl ? GemvShape{sl, 0, 0} : resolve_shape(a, pro, epi);
-    const int RB = (64 / sh.L) * ((sl ? static_NT(a, pro, epi) : kBlock) / 64);
+    const StaticClass sc = static_class(a, pro, epi);
+    const GemvShape sh = sc.L ? GemvShape{sc.L, 0, 0} : resolve_shape(a, pro, epi);
+    const int RB = (64 / sh.L) * ((sc.L ? sc.nt : kBlock) / 64);
     const int n_pass = (a.o + RB - 1) / RB;
-    static const int w13_grid = env_flag("LMRS_W13_GRID", 512), qkv_grid = env_flag("LMRS_QKV_GRID", 4096);
-    int cap = (epi == EPI_CLS) ? 512 : 4096;              // classifier: persistent-style grid, prologue paid once per workgroup
-    if (epi == EPI_SWIGLU) cap = w13_grid;
-    if (epi == EPI_QKV) cap = qkv_grid;
+    int cap = 4096;
+    if (epi == EPI_CLS) cap = 512;                         // classifier: persistent-style grid, prologue paid once per workgroup
+    else if (sc.L && (epi == EPI_SWIGLU || epi == EPI_GELU)) cap = (n_pass + 1) / 2;   // w1w3: two passes per workgroup
     return n_pass < cap ? n_pass : cap;
 }
 
@@ -689,25 +721,17 @@ hipError_t launch_gemv(const GemvArgs& a0, int pro, int epi, hipStream_t s, int 
     if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
     const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
     const size_t smem = gemv_smem(a, pro);
-    if (const int sl = static_L(a, pro, epi)) {
-        const int nt = static_NT(a, pro, epi);
-        static const int split_w13 = env_flag("LMRS_SPLIT_W13", 0), split_w2 = env_flag("LMRS_SPLIT_W2", 0);
-#define XS(n_, l_, p_, e_, nt_, sp_, var_)                                                                  \
-        if (a.n == n_ && sl == l_ && pro == p_ && epi == e_ && nt == nt_ && var_ == sp_) {                  \
-            LMRS_LAUNCH_NT((gemv_static_kernel<n_, l_, p_, e_, nt_, sp_>), grid, nt_, smem, s, a);           \
-            return hipGetLastError();                                                                      \
-        }
-        XS(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 256, 4, split_w13) XS(2048, 8, PRO_RMS_QUANT, EPI_SWIGLU, 256, 8, split_w13)
-        XS(8192, 64, PRO_QUANT, EPI_RESID, 512, 2, split_w2) XS(8192, 64, PRO_QUANT, EPI_RESID, 512, 4, split_w2)
-#undef XS
-#define X(n_, l_, p_, e_, nt_)                                                                             \
-        if (a.n == n_ && sl == l_ && pro == p_ && epi == e_ && nt == nt_) {                                \
-            LMRS_LAUNCH_NT((gemv_static_kernel<n_, l_, p_, e_, nt_>), grid, nt_, smem, s, a);                \
+    const StaticClass sc = static_class(a, pro, epi);
+    if (sc.L) {
+#define X(n_, l_, p_, e_, nt_, q_)                                                                         \
+        if (a.n == n_ && sc.L == l_ && pro == p_ && epi == e_ && sc.nt == nt_ && (a.q4 != 0) == q_) {      \
+            LMRS_LAUNCH_NT((gemv_static_kernel<n_, l_, p_, e_, nt_, q_>), grid, nt_, smem, s, a);            \
             return hipGetLastError();                                                                      \
         }
         LMRS_STATIC_TABLE(X)
 #undef X
     }
+    if (pro == PRO_ADD_RMS_QUANT) return hipErrorInvalidValue;       // static kernels only (callers check gemv_is_static)
     const GemvShape sh = resolve_shape(a, pro, epi);
 #define X(l, u, np, p, e, q)                                                                               \
     if (sh.L == l && sh.U == u && sh.NP == np && pro == p && epi == e && (a.q4 != 0) == q) {              \
@@ -863,6 +887,11 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     ATT_STAMP(2);
 
     // scores (transformer.rs:507-529): one lane per t, sequential dot over the head dims
+    // Gemma's window test uses the position of the FIRST token of a forward_layer call (`pos`, not pos + i, :525): for the
+    // later tokens of a batched call (fill_kv_cache) pos - t wraps around in u32 and the keys after the first token get the
+    // mask value.  win_base >= 0 carries that first position; decode (one token per call) has win_base < 0.
+    int wpos = pos;
+    if (a.gemma) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
     const float sqrt_hs = sqrtf((float)HS);
     float lmax = __uint_as_float(0xff800000u);
     for (int c = 0; c < nchunks; ++c) {
@@ -894,7 +923,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
                 score = score / 50.0f;
                 score = (float)tanh((double)score);
                 score = score * 50.0f;
-                score = score + (((unsigned)(pos - (t0 + tid)) <= 4096u) ? 0.0f : -2.3819763e38f);
+                score = score + (((unsigned)(wpos - (t0 + tid)) <= 4096u) ? 0.0f : -2.3819763e38f);   // :525, u32 arithmetic as in the reference
             }
             att[t0 + tid] = score;
             lmax = fmaxf(lmax, score);

@@ -107,25 +107,29 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
             // The adds are one serial chain; the LDS reads are not.  Two batches of 8 x 16 B ping-pong, with compiler
             // barriers so that the next batch's reads are ISSUED before the current batch's 32 adds (left alone, the
             // scheduler sinks the reads next to their uses and exposes the LDS latency once per 16 adds).
-            constexpr int BF = 8;
-            static_assert(NJ4 % (2 * BF) == 0, "row length must be a multiple of 64 floats");
+            constexpr int BF = 8, NB = NJ4 / BF;               // batches of 8 x 16 B (32 adds each)
+            static_assert(NJ4 % BF == 0, "row length must be a multiple of 32 floats");
             float4 A[BF], B[BF];
 #pragma unroll
             for (int u = 0; u < BF; ++u) A[u] = row[u];
 #pragma unroll
-            for (int j0 = 0; j0 < NJ4; j0 += 2 * BF) {
+            for (int b0 = 0; b0 < NB; b0 += 2) {
+                if (b0 + 1 < NB) {
 #pragma unroll
-                for (int u = 0; u < BF; ++u) B[u] = row[j0 + BF + u];
+                    for (int u = 0; u < BF; ++u) B[u] = row[(b0 + 1) * BF + u];
+                }
                 asm volatile("" : "+v"(p) : : "memory");         // the running sum passes through: the adds below cannot move above the reads
 #pragma unroll
                 for (int u = 0; u < BF; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
-                if (j0 + 2 * BF < NJ4) {
+                if (b0 + 1 < NB) {
+                    if (b0 + 2 < NB) {
 #pragma unroll
-                    for (int u = 0; u < BF; ++u) A[u] = row[j0 + 2 * BF + u];
+                        for (int u = 0; u < BF; ++u) A[u] = row[(b0 + 2) * BF + u];
+                    }
+                    asm volatile("" : "+v"(p) : : "memory");
+#pragma unroll
+                    for (int u = 0; u < BF; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
                 }
-                asm volatile("" : "+v"(p) : : "memory");
-#pragma unroll
-                for (int u = 0; u < BF; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
             }
         }
         const float p0 = __shfl(p, 0), p1 = __shfl(p, 1), p2 = __shfl(p, 2), p3 = __shfl(p, 3);
@@ -204,47 +208,108 @@ __device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NT
     }
 }
 
+// quantize_q4 (reference quantization.rs:69-95) of v[] into LDS: xq4[N/2] packed nibbles, xs[N/128] f32.
+// The LDS copy keeps the reference's packing (even element = low nibble) but stores every nibble XOR 8: (q - 8), the
+// value the reference multiplies (functional.rs:236-240), is the 4-bit two's-complement number with exactly that bit
+// pattern, so v_dot8_i32_i4 on (weights ^ 0x88888888, this) is the group's integer sum with no unpacking at all.
+// Candidates without the per-element division as in vec_quantize_q8: n = rint(x * inv + 8.0); lanes whose value lies
+// within 1e-4 of a rounding boundary, and abnormal groups, redo the reference arithmetic (quant_q4_try, lmrs_device_math.h).
+template <int N, int NTH = kBlk, class F = NoHook>
+__device__ __forceinline__ void vec_quantize_q4(const float4 (&v)[(VecGeom<N, NTH>::NP)], int8_t* xq4, float* xs, unsigned long long* dbg = nullptr, F landed = F()) {
+    constexpr int NP = VecGeom<N, NTH>::NP;
+    const int t = threadIdx.x;
+    float m[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = i * VecGeom<N, NTH>::PER + t * 4;
+        const bool live = VecGeom<N, NTH>::FULL || i < NP - 1 || e < N;
+        m[i] = live ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.0f;
+    }
+    landed();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) m[i] = group32_max(m[i]);
+    if (dbg && t == 0) dbg[6] = wall_clock64();
+    float sc[NP], inv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { sc[i] = m[i] / -8.0f; inv[i] = __builtin_amdgcn_rcpf(sc[i]); }
+    unsigned q[NP][4];
+    float dev[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        dev[i] = 0.0f;
+        q[i][0] = quant_q4_try(v[i].x, inv[i], dev[i]); q[i][1] = quant_q4_try(v[i].y, inv[i], dev[i]);
+        q[i][2] = quant_q4_try(v[i].z, inv[i], dev[i]); q[i][3] = quant_q4_try(v[i].w, inv[i], dev[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (quant_slow(m[i], dev[i])) {
+            q[i][0] = quant_q4(v[i].x, sc[i]); q[i][1] = quant_q4(v[i].y, sc[i]);
+            q[i][2] = quant_q4(v[i].z, sc[i]); q[i][3] = quant_q4(v[i].w, sc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = i * VecGeom<N, NTH>::PER + t * 4;
+        if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) {
+            const unsigned packed = (q[i][0] | (q[i][1] << 4) | (q[i][2] << 8) | (q[i][3] << 12)) ^ 0x8888u;
+            *reinterpret_cast<unsigned short*>(xq4 + (e >> 1)) = (unsigned short)packed;
+            if ((t & 31) == 0) xs[e >> 7] = sc[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// Weight tile: the 16-byte steps one lane holds for one row-pass (Q8_0).
-//   L lanes per row, NC = L/8 clusters, each cluster owns a contiguous segment of U = G/NC groups.
+// Weight tile: the 16-byte steps one lane holds for one row-pass.
+//   L lanes per row; CL lanes (a "cluster") cover one 128-element group: 8 x 16 B for Q8_0, 4 x 16 B for Q4_0;
+//   NC = L/CL clusters, each owning a contiguous segment of U = G/NC groups.
 // ------------------------------------------------------------------------------------------------
-template <int N, int L, int NTH = kBlk> struct RowGeom {
-    static constexpr int G = N / 128, NC = L / 8, U = G / NC;
+template <int N, int L, int NTH = kBlk, bool Q4 = false> struct RowGeom {
+    static constexpr int G = N / 128, CL = Q4 ? 4 : 8, NC = L / CL, U = G / NC;
+    static constexpr int ROWB = Q4 ? N / 2 : N;                    // bytes per weight row
     static constexpr int RW = 64 / L, RB = RW * (NTH / 64);        // rows per wave / per workgroup pass
-    static_assert(G % NC == 0, "row groups must divide over the clusters");
+    static_assert(L % CL == 0 && G % NC == 0, "row groups must divide over the clusters");
     static_assert(U >= 1 && U <= 24, "a cluster's groups must fit one tile");
 };
 
 template <int U> struct WTile { i32x4 w[U]; float sc[U]; };
 
 // steps [U0, U1) of the tile (the whole tile by default)
-template <int N, int L, int U0 = 0, int U1 = RowGeom<N, L>::U>
-__device__ __forceinline__ void tile_issue(WTile<RowGeom<N, L>::U>& t, const int8_t* __restrict__ wq, const float* __restrict__ ws, int row) {
-    using R = RowGeom<N, L>;
-    const int lane = threadIdx.x & 63, r = lane % L, g0 = (r / 8) * R::U, rc = r & 7;
-    const LMRS_GLOBAL i32x4* wrow = as_global(reinterpret_cast<const i32x4*>(wq + (size_t)row * N)) + g0 * 8 + rc;
+template <int N, int L, bool Q4 = false, int U0 = 0, int U1 = RowGeom<N, L, kBlk, Q4>::U>
+__device__ __forceinline__ void tile_issue(WTile<RowGeom<N, L, kBlk, Q4>::U>& t, const int8_t* __restrict__ wq, const float* __restrict__ ws, int row) {
+    using R = RowGeom<N, L, kBlk, Q4>;
+    const int lane = threadIdx.x & 63, r = lane % L, g0 = (r / R::CL) * R::U, rc = r % R::CL;
+    const LMRS_GLOBAL i32x4* wrow = as_global(reinterpret_cast<const i32x4*>(wq + (size_t)row * R::ROWB)) + g0 * R::CL + rc;
     const LMRS_GLOBAL float* srow = as_global(ws) + (size_t)row * R::G + g0;
 #pragma unroll
     for (int u = U0; u < U1; ++u) {
-        t.w[u] = __builtin_nontemporal_load(wrow + u * 8);
+        t.w[u] = __builtin_nontemporal_load(wrow + u * R::CL);
         t.sc[u] = srow[u];
     }
 }
 
-// -> the row's result, valid in the lanes of the row's LAST cluster (r >= L - 8).
-template <int N, int L>
-__device__ __forceinline__ float tile_consume(const WTile<RowGeom<N, L>::U>& t, const int8_t* xq, const float* xs) {
-    using R = RowGeom<N, L>;
-    const int lane = threadIdx.x & 63, r = lane % L, cl = r / 8, g0 = cl * R::U, rc = r & 7;
+// -> the row's result, valid in the lanes of the row's LAST cluster (r >= L - CL).
+template <int N, int L, bool Q4 = false>
+__device__ __forceinline__ float tile_consume(const WTile<RowGeom<N, L, kBlk, Q4>::U>& t, const int8_t* xq, const float* xs) {
+    using R = RowGeom<N, L, kBlk, Q4>;
+    const int lane = threadIdx.x & 63, r = lane % L, cl = r / R::CL, g0 = cl * R::U, rc = r % R::CL;
     float pb[R::U];
 #pragma unroll
     for (int u = 0; u < R::U; ++u) {
-        const i32x4 x = *reinterpret_cast<const i32x4*>(xq + ((g0 + u) * 8 + rc) * 16);
-        int d = __builtin_amdgcn_sdot4(t.w[u].x, x.x, 0, false);
-        d = __builtin_amdgcn_sdot4(t.w[u].y, x.y, d, false);
-        d = __builtin_amdgcn_sdot4(t.w[u].z, x.z, d, false);
-        d = __builtin_amdgcn_sdot4(t.w[u].w, x.w, d, false);
-        d = cluster8_sum(d);
+        const i32x4 x = *reinterpret_cast<const i32x4*>(xq + ((g0 + u) * R::CL + rc) * 16);
+        int d;
+        if constexpr (!Q4) {
+            d = __builtin_amdgcn_sdot4(t.w[u].x, x.x, 0, false);
+            d = __builtin_amdgcn_sdot4(t.w[u].y, x.y, d, false);
+            d = __builtin_amdgcn_sdot4(t.w[u].z, x.z, d, false);
+            d = __builtin_amdgcn_sdot4(t.w[u].w, x.w, d, false);
+            d = cluster8_sum(d);
+        } else {                                      // (nibble - 8) of both operands = signed 4-bit value of nibble ^ 8
+            d = __builtin_amdgcn_sdot8(t.w[u].x ^ (int)0x88888888, x.x, 0, false);
+            d = __builtin_amdgcn_sdot8(t.w[u].y ^ (int)0x88888888, x.y, d, false);
+            d = __builtin_amdgcn_sdot8(t.w[u].z ^ (int)0x88888888, x.z, d, false);
+            d = __builtin_amdgcn_sdot8(t.w[u].w ^ (int)0x88888888, x.w, d, false);
+            d += dpp_i<0xB1>(d); d += dpp_i<0x4E>(d);  // the 4 lanes of the cluster
+        }
         float p = (float)d * t.sc[u];                 // (ival as f32) * w.s[..]
         pb[u] = p * xs[g0 + u];                       //   * x.s[..]
     }
@@ -255,7 +320,7 @@ __device__ __forceinline__ float tile_consume(const WTile<RowGeom<N, L>::U>& t, 
     } else {
 #pragma unroll
         for (int j = 0; j < R::NC; ++j) {
-            const float carry = j == 0 ? 0.0f : __shfl(acc, (lane & ~(L - 1)) + (j - 1) * 8);
+            const float carry = j == 0 ? 0.0f : __shfl(acc, (lane & ~(L - 1)) + (j - 1) * R::CL);
             if (cl == j) {
                 acc = carry;
 #pragma unroll
@@ -264,6 +329,17 @@ __device__ __forceinline__ float tile_consume(const WTile<RowGeom<N, L>::U>& t, 
         }
     }
     return acc;
+}
+
+// GELU(gate) * up, reference transformer.rs:607-616 (f32 cubic, f64 tanh)
+__device__ __forceinline__ float geglu(float gate, float up) {
+    float cube = 0.044715f * gate; cube = cube * gate; cube = cube * gate;
+    const float inner = gate + cube;
+    const double th = tanh(0.7978845608028654 * (double)inner);
+    const float g = 0.5f * (1.0f + (float)th);
+    float val = gate * g;
+    val = val * up;
+    return val;
 }
 
 // SiLU(gate) * up, reference transformer.rs:617-620

@@ -29,6 +29,23 @@ static inline int fast_q(float x, float inv, float scale, float wmax) {
     if (slow) return exact_q(x, scale);
     return (int)n;      /* v_cvt_i32_f32; |n| <= 127 here, asserted below */
 }
+/* Q4_0 activation quantiser (reference src/quantization.rs:69-95): scale = wmax / -8, nibble = clamp(round(x/scale + 8) as u8, 0, 15) */
+static inline unsigned exact_q4(float x, float scale) {
+    float q = roundf(x / scale + 8.0f);
+    if (q != q) return 0;
+    if (q < 0.0f) q = 0.0f;
+    if (q > 15.0f) q = 15.0f;
+    return (unsigned)q;
+}
+static inline unsigned fast_q4(float x, float inv, float scale, float wmax) {
+    int slow = !(wmax > 1.0e-30f && wmax < 1.0e30f);
+    const float s = x * inv + 8.0f;
+    const float n = rintf(s);
+    slow |= fabsf(s - n) > 0.4999f;
+    if (slow) return exact_q4(x, scale);
+    const unsigned q = (unsigned)(int)n;
+    return q < 15u ? q : 15u;
+}
 static uint64_t s = 88172645463325252ull;
 static inline uint32_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 16); }
 static inline float urand(void) { return (float)(rnd() >> 8) / 16777216.0f; }
@@ -54,10 +71,29 @@ int main(void) {
         if (e != fast_q(x, inv, scale, wmax) || e != fast_q(x, nextafterf(inv, INFINITY), scale, wmax) || e != fast_q(x, nextafterf(inv, 0.0f), scale, wmax)) bad++;
         n++;
     }
+    /* the same for Q4_0 */
+    for (long it = 0; it < 200000000L; ++it) {
+        float wmax, x;
+        const uint32_t mode = rnd() & 7;
+        if (mode < 5) { wmax = ldexpf(0.5f + urand(), (int)(rnd() % 40) - 30); x = (2.0f * urand() - 1.0f) * wmax; }
+        else if (mode == 5) { wmax = ldexpf(0.5f + urand(), (int)(rnd() % 250) - 140); x = (2.0f * urand() - 1.0f) * wmax; }
+        else {
+            wmax = ldexpf(0.5f + urand(), (int)(rnd() % 40) - 30);
+            const float sc = wmax / -8.0f; const int k = (int)(rnd() % 17) - 8;       /* x/scale + 8 = k + 8.5 +- a few ulp */
+            x = ((float)k + 0.5f) * sc; uint32_t u; memcpy(&u, &x, 4); u += (rnd() % 9) - 4; memcpy(&x, &u, 4);
+            if (rnd() & 1) x = -x;
+        }
+        if (fabsf(x) > wmax) x = copysignf(wmax, x);
+        const float scale = wmax / -8.0f, inv = 1.0f / scale;
+        const unsigned e = exact_q4(x, scale);
+        if (e != fast_q4(x, inv, scale, wmax) || e != fast_q4(x, nextafterf(inv, -INFINITY), scale, wmax) || e != fast_q4(x, nextafterf(inv, 0.0f), scale, wmax)) bad++;
+        n++;
+    }
     /* degenerate groups */
     const float zs[] = {0.0f, -0.0f, 1e-45f, 3e-39f, INFINITY, NAN};
     for (unsigned i = 0; i < sizeof zs / sizeof *zs; ++i)
-        for (unsigned j = 0; j < sizeof zs / sizeof *zs; ++j) { if (exact_q(zs[j], zs[i] / 127.0f) != fast_q(zs[j], 1.0f / (zs[i] / 127.0f), zs[i] / 127.0f, zs[i])) bad++; n++; }
+        for (unsigned j = 0; j < sizeof zs / sizeof *zs; ++j) { if (exact_q(zs[j], zs[i] / 127.0f) != fast_q(zs[j], 1.0f / (zs[i] / 127.0f), zs[i] / 127.0f, zs[i])) bad++; n++;
+              if (exact_q4(zs[j], zs[i] / -8.0f) != fast_q4(zs[j], 1.0f / (zs[i] / -8.0f), zs[i] / -8.0f, zs[i])) bad++; n++; }
     printf("cases: %llu  mismatches: %llu\n", n, bad);
     return bad != 0;
 }

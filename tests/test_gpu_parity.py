@@ -207,10 +207,13 @@ def test_mini_q4_and_gemma_logits_bit_exact(L, cfg, q):
         tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
-def test_get_embeddings_and_fill_kv_cache(L):
-    img = S.build_image("mini-phi", S.Q8_0, seed=13)
+@pytest.mark.parametrize("cfg,q", [("mini-phi", S.Q8_0), ("mini-gemma", S.Q4_0)])
+def test_get_embeddings_and_fill_kv_cache(L, cfg, q):
+    """mini-gemma: the folded residual form (x += rmsnorm(branch) inside the next GEMV's prologue) must hand the FINISHED
+    residual stream back to fill_kv_cache's caller."""
+    img = S.build_image(cfg, q, seed=13)
     m = L.Transformer(img); orc = O.Oracle(img)
-    toks = S.prompt_tokens("mini-phi", 9, 13)
+    toks = S.prompt_tokens(cfg, 9, 13)
     e_dev = m.get_embeddings(toks); e_ref = orc.get_embeddings(toks)
     assert_bit_equal(e_dev, e_ref, "get_embeddings")
     # empty input is legal in the reference (returns an empty Vec)

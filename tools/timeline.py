@@ -1,5 +1,5 @@
 """Per-kernel timeline of one decode step from the in-kernel wall-clock stamps (LMRS_DEBUG_TIMELINE=1).
-usage: LMRS_DEBUG_TIMELINE=1 python tools/timeline.py [model] [pos]"""
+usage: LMRS_DEBUG_TIMELINE=1 python tools/timeline.py [model] [pos] [q8_0|q4_0]"""
 import os
 import sys
 
@@ -12,7 +12,8 @@ from tools import synth_lmrs as S  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else "llama-3.2-1b"
 npos = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-img = S.build_image(model, S.Q8_0, 1234)
+qt = S.Q4_0 if len(sys.argv) > 3 and sys.argv[3] == "q4_0" else S.Q8_0
+img = S.build_image(model, qt, 1234)
 m = lmrs_amd.Transformer(img)
 prompt = S.prompt_tokens(model, 16, 1234)
 toks, sec = m.generate_greedy(prompt, npos - 15, timing=True)

@@ -454,6 +454,8 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     const int8_t* wq = reinterpret_cast<const int8_t*>(a.wq);
     constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT;
 
+    int pos_pre = 0;
+    if constexpr (EPI == EPI_QKV) pos_pre = a.st->pos;      // the kernel's first load: nothing it has to wait behind
     float4 v[V::NP], nw[V::NP], dl[V::NP], aw[V::NP];
     if constexpr (PRO != PRO_PREQ) {
         if constexpr (PRO == PRO_ADD_RMS_QUANT) { vec_load<N, false, NTH>(dl, a.delta); vec_load<N, false, NTH>(aw, a.add_w); }
@@ -471,6 +473,12 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     WTile<R::U> ta, tb;
     int pass = blockIdx.x;                      // grid <= n_pass
     tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(pass));
+    // Epilogue operands that live in memory are fetched here, under the prologue, instead of as a dependent round trip at
+    // the very end of the kernel: the residual value of the first pass's row (each row has exactly one writer, nobody else
+    // touches it during the launch) and the position the QKV epilogue stores the V row at.
+    // (unconditional, every lane of the row: a load under a lane predicate would cost the kernel its counted vmcnt waits)
+    float resid0 = 0.0f;
+    if constexpr (EPI == EPI_RESID) resid0 = a.out[row_of(pass)];
     // (two-pass launches: issuing the second tile here as well was measured - slower on every model: the more bytes the
     // chip has in flight, the later every workgroup's activation lands)
     __builtin_amdgcn_sched_barrier(0);           // the prologue's first wait must not be scheduled above the tile's loads
@@ -508,12 +516,12 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
         if constexpr (EPI == EPI_STORE) {
             if (valid && writer) a.out[row] = acc;
         } else if constexpr (EPI == EPI_RESID) {
-            if (valid && writer) a.out[row] = a.out[row] + acc;
+            if (valid && writer) a.out[row] = (ps == (int)blockIdx.x ? resid0 : a.out[row]) + acc;
         } else if constexpr (EPI == EPI_QKV) {
             if (valid && writer) {
                 if (row < a.att_dim) a.out[row] = acc;
                 else if (row < a.att_dim + a.kv_dim) a.k_raw[row - a.att_dim] = acc;
-                else a.v_cache[((size_t)a.layer * a.seq_len + a.st->pos) * a.kv_dim + (row - a.att_dim - a.kv_dim)] = acc;
+                else a.v_cache[((size_t)a.layer * a.seq_len + pos_pre) * a.kv_dim + (row - a.att_dim - a.kv_dim)] = acc;
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
             const float up = __shfl_down(acc, L);                       // rows interleaved: 2i gate, 2i+1 up

@@ -42,11 +42,12 @@ struct GemvArgs {
 struct AttnArgs {
     const float* q;          // att_dim raw (un-rotated) query
     const float* k_raw;      // kv_dim raw key of this position
-    float* k_cache; const float* v_cache;     // [layer][seq_len][kv_dim]
+    float* k_cache;          // [layer][kv head][head_size / 4][seq_len][4]: blocked for the score lanes (see attention_body)
+    const float* v_cache;    // [layer][seq_len][kv_dim]
+    int chunk;               // V rows staged through LDS at a time (set by launch_attention)
     const float* rope;       // [seq_len][head_size/2][2] = (fcr, fci)
     float* out;              // att_dim
     int n_heads, n_kv_heads, head_size, seq_len, layer, gemma;
-    int chunk;               // timesteps staged through LDS at a time (set by launch_attention)
     unsigned long long* dbg; // optional: 8 wall-clock stamps (debug timeline)
     const DevState* st;
 };

@@ -827,14 +827,21 @@ __device__ __forceinline__ void att_tstore(const float4 (&rg)[NF], float* tile, 
 
 // ------------------------------------------------------------------------------------------------
 // Attention for one new token: RoPE + scores + softmax + weighted V  (transformer.rs:443-544)
-// One workgroup per query head, head size HS a compile-time constant.  Softmax's sum and the V
-// accumulation are sequential over t in the reference and float addition is not associative, so each
-// stays one serial chain of ADDS on one lane; everything order-free runs in parallel: the scores across
-// t, max, exp, divide, the HS output dims, and the products a_t * v_t[d] (formed by all 256 lanes when the
-// V tile is written to LDS, so the serial part is add-only).
-// K and V rows are staged through LDS in chunks of CH timesteps; all lanes issue their global loads up
-// front (K and V of the first chunk together, before RoPE: the caller does that and hands the registers
-// in); the next chunk's loads are in flight while the current one is consumed.
+// One workgroup per query head, head size HS a compile-time constant.  The reference's sums are sequential - the dot
+// product over the head dims, softmax's sum over t, the V accumulation over t - and float addition is not associative, so
+// each stays one serial chain of adds on one lane; everything order-free runs in parallel: the scores across t (one lane
+// per timestep), max, exp, divide, the HS output dims (one lane per dim) and the products a_t * v_t[d].
+//
+// K: the score chain of timestep t wants k_t[0], k_t[1], .. in ONE lane, so the K cache is kept in the order the lanes
+// read it: k_cache[layer][kv head][d / 4][t][d % 4].  Lane t loads 16 bytes (4 consecutive dims of its own key) per
+// instruction, consecutive lanes consecutive 16-byte words: the keys go straight from memory into the lane that runs the
+// chain - no LDS staging, no transposition, no barrier - and the first batch is in flight across the RoPE step.  (The cache
+// is internal to the library; the reference's API never exposes it.)  The new key, rotated here, is stored to the cache by
+// every head of its kv head (identical values) before the loads that may hit it.
+// V keeps the reference's [t][kv_dim] rows.  The chain of output dim d wants v_0[d], v_1[d], ..: rows are loaded by all
+// 256 lanes (16 B each, coalesced per row), scaled by a_t while they are written to an LDS tile - so the serial part is
+// add-only - and lane d walks down its column.  The whole workgroup's registers are the prefetch buffer: the first chunk
+// of CH rows is in flight from the top of the kernel, the next chunk while the current one is consumed.
 // COH: q, the raw key and the V row of this position were produced by other workgroups of the SAME launch
 // (persistent engine) and are read / the output written with agent-scope accesses; the V row of `pos` is
 // then patched in from a coherent read instead of the (possibly stale) prefetched copy.
@@ -845,9 +852,61 @@ __device__ __forceinline__ void att_tstore(const float4 (&rg)[NF], float* tile, 
 // request order: issued after them, these few bytes would only arrive behind the whole first K/V chunk).
 struct AttPre { float q0, q1, k0, k1; float2 cs; };
 
-template <int HS, int NF, bool COH, bool PRE = false>
-__device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, float4 (&kreg)[NF], float4 (&vreg)[NF], uint64_t etab,
-                                               const AttPre& pre = AttPre()) {
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// K of one kv head, blocked for the score lanes: [HS / 4][seq_len][4]
+__device__ __forceinline__ float* att_k_head(const AttnArgs& a, int kvh, int hs) {
+    return a.k_cache + ((size_t)a.layer * a.n_kv_heads + kvh) * hs * (size_t)a.seq_len;
+}
+// NG 16-byte words of this lane's key (dim groups g0 .. g0+NG-1): SGPR resource + scalar group offset + lane offset,
+// one instruction per load and no address arithmetic
+template <int NG>
+__device__ __forceinline__ void att_kload(f32x4v (&dst)[NG], __amdgpu_buffer_rsrc_t krs, int voff, int g0, int S) {
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const auto t = __builtin_amdgcn_raw_buffer_load_b128(krs, voff, (g0 + u) * S * 16, 0);
+        dst[u] = f32x4v{__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3])};
+    }
+}
+template <int NG>
+__device__ __forceinline__ float att_kuse(float score, const f32x4v (&src)[NG], const float4* q4, int g0) {
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const float4 qq = q4[g0 + u];
+        float pr;
+        pr = qq.x * src[u].x; score = score + pr;
+        pr = qq.y * src[u].y; score = score + pr;
+        pr = qq.z * src[u].z; score = score + pr;
+        pr = qq.w * src[u].w; score = score + pr;
+    }
+    return score;
+}
+// The score chain of this lane's timestep: kk holds the first batch of its key (already loaded), further batches
+// ping-pong between kk and kb, one batch of loads ahead of the adds.  The running sum passes through an opaque asm after
+// every batch: that anchors the batch's adds between its neighbours' loads (left alone, instruction selection sinks all the
+// arithmetic below all the loads, and a whole key + q in registers does not fit for the big heads).
+template <int HS, int NG>
+__device__ __forceinline__ float att_score_chain(f32x4v (&kk)[NG], __amdgpu_buffer_rsrc_t krs, int voff, const float* q, int S) {
+    constexpr int HS4 = HS / 4;
+    f32x4v kb[NG];
+    float score = 0.0f;
+    const float4* q4 = reinterpret_cast<const float4*>(q);
+#pragma unroll
+    for (int g0 = 0; g0 < HS4; g0 += 2 * NG) {
+        if (g0 + NG < HS4) att_kload<NG>(kb, krs, voff, g0 + NG, S);
+        score = att_kuse<NG>(score, kk, q4, g0);
+        asm volatile("" : "+v"(score) : : "memory");
+        if (g0 + NG < HS4) {
+            if (g0 + 2 * NG < HS4) att_kload<NG>(kk, krs, voff, g0 + 2 * NG, S);
+            score = att_kuse<NG>(score, kb, q4, g0 + NG);
+            asm volatile("" : "+v"(score) : : "memory");
+        }
+    }
+    return score;
+}
+
+// GEMMA: score soft-cap + window mask (a compile-time switch: the f64 tanh is ~230 instructions and a dozen registers)
+template <int HS, int NF, bool COH, bool PRE = false, bool GEMMA = false>
+__device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, uint64_t etab, const AttPre& pre = AttPre()) {
     static_assert(!PRE || HS / 2 <= kBlock, "one RoPE pair per lane");
     constexpr int half = HS / 2, HS4 = HS / 4, RS = HS + 4;
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
@@ -863,8 +922,18 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     float* att = tile + (size_t)(CH + 32) * RS;       // T (+32 floats of zero padding, +32 of read-ahead)
     const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
     const int nchunks = (T + CH - 1) / CH;
-    const float* kbase = a.k_cache + loff + kvh * HS;
     const float* vbase = a.v_cache + loff + kvh * HS;
+    const int S = a.seq_len;
+    float* kT = att_k_head(a, kvh, HS);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(kT, 0, HS * S * 4, 0x00020000);
+    // ---- this lane's key (timesteps 0..255), first batch of dims, and the first V chunk: in flight across the RoPE step
+    constexpr int KG = HS / 4 <= 32 ? HS / 4 : 16;    // 16-byte words per batch
+    static_assert((HS / 4) % KG == 0, "head size");
+    const int tc0 = tid < T ? tid : T - 1;            // lanes past the sequence re-read its last key (no predication)
+    f32x4v kk[KG];
+    att_kload<KG>(kk, krs, tc0 * 16, 0, S);
+    float4 vreg[NF];
+    att_gload<HS, NF>(vreg, vbase, 0, T, CH, kv_dim);  // row `pos` of V was stored by the QKV kernel (COH: patched from vn)
 
     // RoPE (transformer.rs:480-491) with the host-built (fcr, fci) table
     for (int j = tid; j < half; j += kBlock) {
@@ -881,62 +950,49 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
             const float r0 = a0 - a1, r1 = b0 + b1;
             kn[j] = r0; kn[j + half] = r1;
-            if (h % kv_mul == 0) {                   // one writer per kv head (read back only by later launches)
-                a.k_cache[loff + (size_t)pos * kv_dim + kvh * HS + j] = r0;
-                a.k_cache[loff + (size_t)pos * kv_dim + kvh * HS + j + half] = r1;
-            }
+            // Every head of the kv head stores the (identical) new key: the score loads below then find it in memory like
+            // every other key - the waves of a workgroup share the CU's L1, so store, vmcnt(0), barrier, load is coherent -
+            // and later launches read it from there anyway.
+            kT[(((size_t)(j >> 2) * S + pos) << 2) + (j & 3)] = r0;
+            kT[(((size_t)((j + half) >> 2) * S + pos) << 2) + ((j + half) & 3)] = r1;
         }
         if constexpr (COH) {
             vn[j] = ld_f32<true>(vbase + (size_t)pos * kv_dim + j);
             vn[j + half] = ld_f32<true>(vbase + (size_t)pos * kv_dim + j + half);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the key stores have reached the cache hierarchy (and the batches loaded above have landed)
     lds_barrier();
     ATT_STAMP(2);
+    if (tc0 == pos) {                                  // batch 0 was loaded before the new key existed: patch it from LDS
+#pragma unroll
+        for (int u = 0; u < KG; ++u) { const float4 t4 = reinterpret_cast<const float4*>(kn)[u]; kk[u] = f32x4v{t4.x, t4.y, t4.z, t4.w}; }
+    }
 
-    // scores (transformer.rs:507-529): one lane per t, sequential dot over the head dims
+    // ---- scores (transformer.rs:507-529): one lane per t, sequential dot over the head dims
     // Gemma's window test uses the position of the FIRST token of a forward_layer call (`pos`, not pos + i, :525): for the
     // later tokens of a batched call (fill_kv_cache) pos - t wraps around in u32 and the keys after the first token get the
     // mask value.  win_base >= 0 carries that first position; decode (one token per call) has win_base < 0.
     int wpos = pos;
-    if (a.gemma) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
+    if constexpr (GEMMA) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
     const float sqrt_hs = sqrtf((float)HS);
     float lmax = __uint_as_float(0xff800000u);
-    for (int c = 0; c < nchunks; ++c) {
-        const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore<HS, NF, false>(kreg, tile, nullptr, t0, T, CH, pos, kn);    // row `pos` comes from the rotated key just computed
-        lds_barrier();
-        if (c + 1 < nchunks) att_gload<HS, NF>(kreg, kbase, t0 + CH, T, CH, kv_dim);
-        if (c == 0) ATT_STAMP(3);
-        if (tid < ct) {
-            const float4* kr = reinterpret_cast<const float4*>(tile + tid * RS);
-            const float4* qr = reinterpret_cast<const float4*>(q);
-            float score = 0.0f;
-#pragma unroll
-            for (int d0 = 0; d0 < HS4; d0 += 16) {                 // 16 x 16 B of the row in flight, then 64 serial adds
-                float4 kk[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) if (d0 + u < HS4) kk[u] = kr[d0 + u];
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (d0 + u < HS4) {
-                        const float4 qq = qr[d0 + u];
-                        float pr;
-                        pr = qq.x * kk[u].x; score = score + pr; pr = qq.y * kk[u].y; score = score + pr;
-                        pr = qq.z * kk[u].z; score = score + pr; pr = qq.w * kk[u].w; score = score + pr;
-                    }
-            }
-            score = score / sqrt_hs;
-            if (a.gemma) {                                 // transformer.rs:518-526
-                score = score / 50.0f;
-                score = (float)tanh((double)score);
-                score = score * 50.0f;
-                score = score + (((unsigned)(wpos - (t0 + tid)) <= 4096u) ? 0.0f : -2.3819763e38f);   // :525, u32 arithmetic as in the reference
-            }
-            att[t0 + tid] = score;
-            lmax = fmaxf(lmax, score);
+    auto finish_score = [&](float score, int t) __attribute__((always_inline)) {
+        score = score / sqrt_hs;
+        if constexpr (GEMMA) {                         // transformer.rs:518-526
+            score = score / 50.0f;
+            score = (float)tanh((double)score);
+            score = score * 50.0f;
+            score = score + (((unsigned)(wpos - t) <= 4096u) ? 0.0f : -2.3819763e38f);   // :525, u32 arithmetic as in the reference
         }
-        lds_barrier();
+        if (t < T) { att[t] = score; lmax = fmaxf(lmax, score); }
+    };
+    finish_score(att_score_chain<HS, KG>(kk, krs, tc0 * 16, q, S), tid);                 // timesteps 0..255
+    for (int t0 = kBlock; t0 < T; t0 += kBlock) {                                        // longer sequences: further passes
+        const int t = t0 + tid, tc = t < T ? t : T - 1;
+        f32x4v k0[KG];
+        att_kload<KG>(k0, krs, tc * 16, 0, S);
+        finish_score(att_score_chain<HS, KG>(k0, krs, tc * 16, q, S), t);
     }
     ATT_STAMP(4);
     // softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
@@ -983,25 +1039,21 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     ATT_STAMP(7);
 }
 
-template <int HS>
+template <int HS, bool GEMMA>
 __global__ __launch_bounds__(kBlock) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int h = blockIdx.x, kvh = h / (a.n_heads / a.n_kv_heads), kv_dim = a.n_kv_heads * HS;
+    const int h = blockIdx.x, kvh = h / (a.n_heads / a.n_kv_heads);
     ATT_STAMP(0);
     const uint64_t etab = exp2f_tab_lane();
-    float4 kreg[kAttF4], vreg[kAttF4];
-    const size_t loff = (size_t)a.layer * a.seq_len * kv_dim;
     constexpr int half = HS / 2;
     const int j = threadIdx.x < half ? (int)threadIdx.x : 0;
-    const int pos = a.st->pos, T = pos + 1;                 // first: the K/V loads depend on it
+    const int pos = a.st->pos;                              // first: the K/V loads depend on it
     AttPre pre;                                             // RoPE inputs ahead of the K/V loads (a CU returns loads in request order)
     pre.q0 = a.q[h * HS + j]; pre.q1 = a.q[h * HS + j + half];
     pre.k0 = a.k_raw[kvh * HS + j]; pre.k1 = a.k_raw[kvh * HS + j + half];
     pre.cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
-    att_gload<HS, kAttF4>(kreg, a.k_cache + loff + kvh * HS, 0, T, a.chunk, kv_dim);   // row `pos` of K is not in the cache yet (patched from kn); its load is harmless
-    att_gload<HS, kAttF4>(vreg, a.v_cache + loff + kvh * HS, 0, T, a.chunk, kv_dim);   // row `pos` of V was stored by the QKV kernel
     ATT_STAMP(1);
-    attention_body<HS, kAttF4, false, true>(a, h, pos, smem, kreg, vreg, etab, pre);
+    attention_body<HS, kAttF4, false, true, GEMMA>(a, h, pos, smem, etab, pre);
 }
 
 static size_t attention_smem(int head_size, int chunk, int seq_len) {
@@ -1014,15 +1066,19 @@ int attention_chunk(int head_size) {
     return ch < 32 ? 32 : ch;
 }
 
-template <int HS>
-static hipError_t launch_attention_hs(const AttnArgs& a, size_t smem, hipStream_t s) {
+template <int HS, bool GEMMA>
+static hipError_t launch_attention_hsg(const AttnArgs& a, size_t smem, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HS, GEMMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_kernel<HS>, dim3(a.n_heads), dim3(kBlock), smem, s, a);
+    hipLaunchKernelGGL((attention_kernel<HS, GEMMA>), dim3(a.n_heads), dim3(kBlock), smem, s, a);
     return hipGetLastError();
+}
+template <int HS>
+static hipError_t launch_attention_hs(const AttnArgs& a, size_t smem, hipStream_t s) {
+    return a.gemma ? launch_attention_hsg<HS, true>(a, smem, s) : launch_attention_hsg<HS, false>(a, smem, s);
 }
 
 hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {

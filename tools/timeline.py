@@ -43,8 +43,8 @@ for k, v in tot.items():
     print(f"  {k:7s} n={len(v):3d}  {a[:,0].mean():7.2f} {a[:,1].mean():7.2f} {a[:,2].mean():7.2f} {a[:,3].mean():7.2f}")
 att = tl[1::5][:L] if NK == 5 else tl[0::NK][:L]
 d = (att - att[:, :1]) / 100.0
-print("attention block0 stamps (us from start): loads-issued, rope-done, k-in-lds, scores-done, softmax-done, v-in-lds, end")
-print("   ", np.round(d[:, [1, 2, 3, 4, 5, 6, 7]].mean(axis=0), 2))
+print("attention block0 stamps (us from start): rope-inputs-issued, rope-done, scores-done, softmax-done, v-in-lds, end")
+print("   ", np.round(d[:, [1, 2, 4, 5, 6, 7]].mean(axis=0), 2))
 for nm, off in (("wo", 2), ("w2", 4)):
     if NK == 5:
         g = tl[off::5][:L]; d = (g - g[:, :1]) / 100.0

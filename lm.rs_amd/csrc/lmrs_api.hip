@@ -69,6 +69,8 @@ struct lmrs_ctx {
     // pinned host
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
+    // batched forward_layer (fill_kv_cache): device buffers for kPrefillTokens tokens, allocated on first use
+    float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr; int8_t* pf_xq = nullptr;
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
@@ -682,6 +684,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->g_step) hipGraphExecDestroy(c->g_step);
     if (c->g_layers) hipGraphExecDestroy(c->g_layers);
+    for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) hipHostFree(c->h_logits);
     if (c->h_tok) hipHostFree(c->h_tok);
@@ -751,11 +754,92 @@ extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, s
     return 0;
 }
 
+// ------------------------------------------------------------------ batched forward_layer on the matrix cores
+constexpr int kPrefillTokens = 128;
+
+// Q8_0 Llama / Phi shapes on one GPU (the GEMM needs whole 16-row tiles and the per-token prologues their static shapes);
+// everything else takes the token-by-token path below (same results).
+static bool prefill_batched_ok(const lmrs_ctx* c) {
+    const lmrs_args& a = c->args;
+    if (getenv("LMRS_NO_BATCHED_PREFILL")) return false;
+    if (c->q4 || a.q_type != LMRS_Q8_0 || a.model_type == LMRS_GEMMA || c->world > 1 || c->comm || !c->g_layers) return false;
+    if (!rows_prologue_supported((int)a.dim) || !rows_prologue_supported(c->att_dim) || !rows_prologue_supported((int)a.hidden_dim)) return false;
+    if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
+    return (c->att_dim + 2 * c->kv_dim) % 16 == 0 && c->kv_dim % 4 == 0;
+}
+
+static int prefill_alloc(lmrs_ctx* c) {
+    if (c->pf_x) return 0;
+    const lmrs_args& a = c->args;
+    const size_t B = kPrefillTokens, wide = std::max<size_t>(std::max<size_t>(a.dim, a.hidden_dim), (size_t)c->att_dim);
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_x), B * a.dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_q), B * c->att_dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_k), B * c->kv_dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_ao), B * c->att_dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_h), B * a.hidden_dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_xq), B * wide));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_xs), B * (wide / 128) * 4));
+    return 0;
+}
+
+// forward_layer(sl = m) for every layer over tokens at positions p0 .. p0+m-1 whose embeddings sit in c->pf_x
+static int prefill_layers(lmrs_ctx* c, int m, int p0) {
+    const lmrs_args& a = c->args;
+    const int dim = (int)a.dim, hid = (int)a.hidden_dim, att = c->att_dim, kv = c->kv_dim;
+    for (uint32_t l = 0; l < a.n_layers; ++l) {
+        const DevLayer& L = c->layers[l];
+        GemmArgs g{};
+        g.xq = c->pf_xq; g.xs = c->pf_xs; g.n_tok = m;
+        // rmsnorm + quantize | Wqkv | q, raw k, v rows -> cache                      (transformer.rs:409-431)
+        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, a.rms_norm_eps, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
+        g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
+        HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
+        // RoPE, keys into the cache; attention per (token, head)                       (:443-544)
+        HIP_OK(launch_rope_rows(c->pf_q, c->pf_k, c->k_cache, c->rope, (int)a.n_heads, (int)a.n_kv_heads, (int)a.head_size, (int)a.seq_len, (int)l, p0, m, c->stream));
+        AttnArgs t{};
+        t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
+        t.n_heads = (int)a.n_heads; t.n_kv_heads = (int)a.n_kv_heads; t.head_size = (int)a.head_size; t.seq_len = (int)a.seq_len; t.layer = (int)l;
+        t.gemma = 0; t.st = c->st;
+        HIP_OK(launch_attention_rows(t, p0, m, c->stream));
+        // quantize | Wo | x += ...                                                      (:550-576)
+        HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, 0.f, 0, att, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.wo; g.ws = L.so; g.n = att; g.o = dim; g.out = c->pf_x;
+        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
+        // rmsnorm + quantize | W1, W3 | silu(gate) * up                                 (:578-624)
+        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, a.rms_norm_eps, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * hid; g.out = c->pf_h;
+        HIP_OK(launch_gemm_q8(g, EPI_SWIGLU, c->stream));
+        // quantize | W2 | x += ...                                                      (:630-654)
+        HIP_OK(launch_rows_prologue(c->pf_h, nullptr, 0.f, 0, hid, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.w2; g.ws = L.s2; g.n = hid; g.o = dim; g.out = c->pf_x;
+        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
+    }
+    return 0;
+}
+
 extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, uint32_t curr_pos, uint32_t* new_pos) {
     if (!c || !embeddings) return fail("NULL argument");
     if ((size_t)curr_pos + n > c->args.seq_len) return fail("positions out of range");
     if (!c->g_layers) return fail("fill_kv_cache is not built for row-sharded contexts");
     HIP_OK(hipSetDevice(c->device));
+    if (prefill_batched_ok(c) && n > 1) {
+        // forward_layer(sl = n): GEMMs over the token batch on the int8 matrix cores, kPrefillTokens tokens at a time
+        // (a later chunk only needs the K/V rows of the earlier ones, exactly as inside the reference's single call).
+        if (prefill_alloc(c)) return -1;
+        const size_t dim = c->args.dim;
+        for (uint32_t i0 = 0; i0 < n; i0 += kPrefillTokens) {
+            const int m = (int)std::min<uint32_t>(kPrefillTokens, n - i0);
+            HIP_OK(hipMemcpyAsync(c->pf_x, embeddings + (size_t)i0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, c->stream));
+            if (prefill_layers(c, m, (int)(curr_pos + i0))) return -1;
+            HIP_OK(hipMemcpyAsync(embeddings + (size_t)i0 * dim, c->pf_x, (size_t)m * dim * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (set_state(c, curr_pos + n, 0)) return -1;
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (check_err(c)) return -1;
+        if (new_pos) *new_pos = curr_pos + n;
+        return 0;
+    }
     // forward_layer(sl = n) for every layer is, value for value, n single-token passes through the
     // layers (causal; each token's arithmetic only sees tokens <= itself), so the decode graph is reused.
     const size_t dim = c->args.dim;
@@ -911,6 +995,13 @@ extern "C" int lmrs_op_matmul_q8(int device, float* xout, const int8_t* xq, cons
     HIP_OK(hipMemcpy(dw, wq, o * n, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dws, ws, o * G * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemset(dout, 0, sl * o * 4));
     const size_t o4 = o / 4 * 4;                       // par_chunks_exact_mut(4): tail rows are never written
+    if (sl > 1 && n % 256 == 0 && o % 16 == 0) {       // a token batch: the matrix-core kernel of the batched forward_layer
+        GemmArgs g{}; g.wq = dw; g.ws = static_cast<float*>(dws); g.xq = static_cast<const int8_t*>(dx); g.xs = static_cast<const float*>(dxs);
+        g.n = (int)n; g.o = (int)o; g.n_tok = (int)sl; g.out = static_cast<float*>(dout);
+        HIP_OK(launch_gemm_q8(g, EPI_STORE, nullptr));
+        HIP_OK(hipMemcpy(xout, dout, sl * o * 4, hipMemcpyDeviceToHost));
+        return 0;
+    }
     for (size_t t = 0; t < sl && o4; ++t) {
         GemvArgs g{}; g.wq = dw; g.ws = static_cast<float*>(dws); g.n = (int)n; g.o = (int)o4;
         g.xq_in = static_cast<char*>(dx) + t * n; g.xs_in = static_cast<float*>(dxs) + t * G; g.out = static_cast<float*>(dout) + t * o;

@@ -905,7 +905,8 @@ __device__ __forceinline__ float att_score_chain(f32x4v (&kk)[NG], __amdgpu_buff
 }
 
 // GEMMA: score soft-cap + window mask (a compile-time switch: the f64 tanh is ~230 instructions and a dozen registers)
-template <int HS, int NF, bool COH, bool PRE = false, bool GEMMA = false>
+// ROT (batched prefill): q is already rotated and the key of `pos` already in the cache (rope_rows_kernel).
+template <int HS, int NF, bool COH, bool PRE = false, bool GEMMA = false, bool ROT = false>
 __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, uint64_t etab, const AttPre& pre = AttPre()) {
     static_assert(!PRE || HS / 2 <= kBlock, "one RoPE pair per lane");
     constexpr int half = HS / 2, HS4 = HS / 4, RS = HS + 4;
@@ -935,8 +936,9 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     float4 vreg[NF];
     att_gload<HS, NF>(vreg, vbase, 0, T, CH, kv_dim);  // row `pos` of V was stored by the QKV kernel (COH: patched from vn)
 
+    if constexpr (ROT) { for (int j = tid; j < HS; j += kBlock) q[j] = a.q[h * HS + j]; }
     // RoPE (transformer.rs:480-491) with the host-built (fcr, fci) table
-    for (int j = tid; j < half; j += kBlock) {
+    for (int j = tid; j < (ROT ? 0 : half); j += kBlock) {
         float2 cs;
         if constexpr (PRE) cs = pre.cs; else cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
         const float fcr = cs.x, fci = cs.y;
@@ -964,7 +966,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the key stores have reached the cache hierarchy (and the batches loaded above have landed)
     lds_barrier();
     ATT_STAMP(2);
-    if (tc0 == pos) {                                  // batch 0 was loaded before the new key existed: patch it from LDS
+    if (!ROT && tc0 == pos) {                          // batch 0 was loaded before the new key existed: patch it from LDS
 #pragma unroll
         for (int u = 0; u < KG; ++u) { const float4 t4 = reinterpret_cast<const float4*>(kn)[u]; kk[u] = f32x4v{t4.x, t4.y, t4.z, t4.w}; }
     }
@@ -1329,6 +1331,7 @@ hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st) {
     return hipGetLastError();
 }
 
+#include "lmrs_prefill.inc"
 #include "lmrs_fused.inc"
 
 }  // namespace lmrs

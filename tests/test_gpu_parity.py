@@ -207,6 +207,37 @@ def test_mini_q4_and_gemma_logits_bit_exact(L, cfg, q):
         tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
+@pytest.mark.parametrize("n,o,sl", [(256, 64, 5), (2048, 3072, 70), (8192, 2048, 33), (3072, 48, 129)])
+def test_matmul_q8_token_batch_on_matrix_cores(L, n, o, sl):
+    """matmul_q8 over sl tokens (functional.rs:173-214 with sl > 1): the int8-MFMA kernel of the batched forward_layer.
+    Integer group sums are exact whatever their order; the float combine keeps the reference's group order per element:
+    bit-equal to the CPU path.  Ragged token counts (not multiples of 16 / 64) and several token blocks."""
+    rng = np.random.default_rng(n + o + sl)
+    wq, ws = _rand_q8(rng, o, n)
+    x = (rng.standard_normal(sl * n) * rng.uniform(0.1, 4.0, sl).repeat(n)).astype(np.float32)
+    xq, xs = O.quantize(x)
+    got = L.matmul_q8(xq, xs, wq, ws, n, o, sl=sl)
+    ref = O.matmul_q8(xq, xs, wq, ws, n, o, sl=sl)
+    assert_bit_equal(got, ref, f"gemm {n}x{o}, {sl} tokens")
+
+
+@pytest.mark.parametrize("cfg,n_tok,pos0", [("mini-llama", 70, 5), ("mini-llama3b", 33, 0), ("mini-phi", 140, 2)])
+def test_fill_kv_cache_batched_prefill(L, cfg, n_tok, pos0):
+    """forward_layer(sl = n) as GEMMs over the token batch (more than one 64-token block, more than one 128-token chunk):
+    the mutated embeddings, and the decode steps that continue on the prefilled KV cache, are bit-identical to the CPU path."""
+    img = S.build_image(cfg, S.Q8_0, seed=21)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    toks = S.prompt_tokens(cfg, n_tok, 21)
+    a = m.get_embeddings(toks); b = orc.get_embeddings(toks)
+    assert m.fill_kv_cache(a, pos0) == orc.fill_kv_cache(b, pos0) == pos0 + n_tok
+    assert_bit_equal(a, b, "residual stream after the batched layers")
+    t = 7
+    for pos in range(pos0 + n_tok, pos0 + n_tok + 3):
+        lo = orc.forward(t, pos)
+        assert_bit_equal(m.forward(t, pos), lo, f"decode at {pos} on the prefilled cache")
+        t = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+
+
 @pytest.mark.parametrize("cfg,q", [("mini-phi", S.Q8_0), ("mini-gemma", S.Q4_0)])
 def test_get_embeddings_and_fill_kv_cache(L, cfg, q):
     """mini-gemma: the folded residual form (x += rmsnorm(branch) inside the next GEMV's prologue) must hand the FINISHED

@@ -755,7 +755,7 @@ extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, s
 }
 
 // ------------------------------------------------------------------ batched forward_layer on the matrix cores
-constexpr int kPrefillTokens = 256;
+constexpr int kPrefillTokens = 512;
 
 // Q8_0 Llama / Phi shapes on one GPU (the GEMM needs whole 16-row tiles and the per-token prologues their static shapes);
 // everything else takes the token-by-token path below (same results).

@@ -221,9 +221,9 @@ def test_matmul_q8_token_batch_on_matrix_cores(L, n, o, sl):
     assert_bit_equal(got, ref, f"gemm {n}x{o}, {sl} tokens")
 
 
-@pytest.mark.parametrize("cfg,n_tok,pos0", [("mini-llama", 70, 5), ("mini-llama3b", 33, 0), ("mini-phi", 140, 2)])
+@pytest.mark.parametrize("cfg,n_tok,pos0", [("mini-llama", 70, 5), ("mini-llama3b", 33, 0), ("mini-phi", 140, 2), ("mini-llama-long", 600, 3)])
 def test_fill_kv_cache_batched_prefill(L, cfg, n_tok, pos0):
-    """forward_layer(sl = n) as GEMMs over the token batch (more than one 64-token block, more than one 128-token chunk):
+    """forward_layer(sl = n) as GEMMs over the token batch (more than one 64-token block; 600 tokens: more than one 512-token chunk):
     the mutated embeddings, and the decode steps that continue on the prefilled KV cache, are bit-identical to the CPU path."""
     img = S.build_image(cfg, S.Q8_0, seed=21)
     m = L.Transformer(img); orc = O.Oracle(img)

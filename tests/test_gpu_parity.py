@@ -207,11 +207,12 @@ def test_mini_q4_and_gemma_logits_bit_exact(L, cfg, q):
         tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
-@pytest.mark.parametrize("n,o,sl", [(256, 64, 5), (2048, 3072, 70), (8192, 2048, 33), (3072, 48, 129)])
+@pytest.mark.parametrize("n,o,sl", [(256, 64, 5), (2048, 3072, 70), (8192, 2048, 33), (3072, 48, 129), (256, 16384, 130), (512, 16400, 257)])
 def test_matmul_q8_token_batch_on_matrix_cores(L, n, o, sl):
     """matmul_q8 over sl tokens (functional.rs:173-214 with sl > 1): the int8-MFMA kernel of the batched forward_layer.
     Integer group sums are exact whatever their order; the float combine keeps the reference's group order per element:
-    bit-equal to the CPU path.  Ragged token counts (not multiples of 16 / 64) and several token blocks."""
+    bit-equal to the CPU path.  Ragged token counts (not multiples of 16 / 64) and several token blocks; the last two shapes
+    have enough 128 x 128 tiles for the LDS-tiled kernel (ragged rows and tokens there too)."""
     rng = np.random.default_rng(n + o + sl)
     wq, ws = _rand_q8(rng, o, n)
     x = (rng.standard_normal(sl * n) * rng.uniform(0.1, 4.0, sl).repeat(n)).astype(np.float32)

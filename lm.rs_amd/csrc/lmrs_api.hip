@@ -865,10 +865,24 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     HIP_OK(hipSetDevice(c->device));
     memcpy(c->h_tok, prompt, n_prompt * 4);
     HIP_OK(hipMemcpyAsync(c->tokens + start_pos, c->h_tok, n_prompt * 4, hipMemcpyHostToDevice, c->stream));
-    if (set_state(c, start_pos, start_pos + (uint32_t)n_prompt)) return -1;
     HIP_OK(hipEventRecord(c->ev0, c->stream));
+    // The reference feeds the prompt token by token and discards every logits vector but the last (chat.rs:188-193): all
+    // prompt tokens except the last only have to leave their K/V rows behind, which is forward_layer over a batch - the
+    // matrix-core path of fill_kv_cache, value for value what the per-token passes produce.
+    size_t done = 0;
+    if (n_prompt >= 9 && prefill_batched_ok(c)) {
+        if (prefill_alloc(c)) return -1;
+        const size_t m_total = n_prompt - 1;
+        for (size_t i0 = 0; i0 < m_total; i0 += kPrefillTokens) {
+            const int m = (int)std::min<size_t>(kPrefillTokens, m_total - i0);
+            HIP_OK(launch_dequant_rows(c->emb_q, c->emb_s, c->q4, c->tokens + start_pos + i0, m, (int)c->args.dim, c->pf_x, c->stream));
+            if (prefill_layers(c, m, (int)(start_pos + i0))) return -1;
+        }
+        done = m_total;
+    }
+    if (set_state(c, start_pos + (uint32_t)done, start_pos + (uint32_t)n_prompt)) return -1;
     HIP_OK(launch_embed(embed_args(c), c->stream));
-    for (size_t s = 0; s < steps; ++s) if (launch_step(c)) return -1;
+    for (size_t s = done; s < steps; ++s) if (launch_step(c)) return -1;
     HIP_OK(hipEventRecord(c->ev1, c->stream));
     if (n_new) HIP_OK(hipMemcpyAsync(c->h_tok, c->tokens + start_pos + n_prompt, (size_t)n_new * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));

@@ -239,6 +239,22 @@ def test_fill_kv_cache_batched_prefill(L, cfg, n_tok, pos0):
         t = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
+@pytest.mark.parametrize("cfg,n_prompt", [("mini-llama", 200), ("mini-phi", 90)])
+def test_generate_greedy_with_a_long_prompt(L, cfg, n_prompt):
+    """generate_greedy feeds all prompt tokens but the last through the batched forward_layer (only their K/V rows matter,
+    chat.rs:188-193 discards those logits): same token ids as the token-by-token CPU path, and as the per-token device path."""
+    img = S.build_image(cfg, S.Q8_0, seed=31)
+    prompt = S.prompt_tokens(cfg, n_prompt, 31)
+    m = L.Transformer(img)
+    got = m.generate_greedy(prompt, 20)
+    ref = O.Oracle(img).generate_greedy(prompt, 20)
+    assert (got == ref).all(), f"first mismatch at {int(np.flatnonzero(got != ref)[0])}"
+    # continuing from the same cache with the per-token API gives the oracle's logits
+    orc = O.Oracle(img); orc.generate_greedy(prompt, 20)
+    pos = n_prompt + 19
+    assert_bit_equal(m.forward(int(got[-1]), pos), orc.forward(int(ref[-1]), pos), "decode after prompt + 20 tokens")
+
+
 @pytest.mark.parametrize("cfg,q", [("mini-phi", S.Q8_0), ("mini-gemma", S.Q4_0)])
 def test_get_embeddings_and_fill_kv_cache(L, cfg, q):
     """mini-gemma: the folded residual form (x += rmsnorm(branch) inside the next GEMV's prologue) must hand the FINISHED

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     /* Q8_0, dim 2048 / hidden 8192: Llama-3.2-1B */                                                                    \
     X(2048, 32, PRO_RMS_QUANT, EPI_QKV, 256, false) X(2048, 32, PRO_QUANT, EPI_RESID, 256, false) X(2048, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256, false) \
     X(2048, 8, PRO_RMS_QUANT, EPI_CLS, 256, false) X(2048, 32, PRO_PREQ, EPI_STORE, 256, false) X(2048, 8, PRO_PREQ, EPI_STORE, 256, false) \
-    X(8192, 64, PRO_QUANT, EPI_RESID, 512, false) X(8192, 32, PRO_PREQ, EPI_STORE, 256, false)                          \
+    X(8192, 64, PRO_QUANT, EPI_RESID, 512, false) X(8192, 32, PRO_PREQ, EPI_STORE, 256, false) \
     /* Q8_0, dim 3072: Llama-3.2-3B, Phi-3.5 */                                                                         \
     X(3072, 32, PRO_RMS_QUANT, EPI_QKV, 256, false) X(3072, 16, PRO_RMS_QUANT, EPI_QKV, 256, false) X(3072, 32, PRO_QUANT, EPI_RESID, 256, false) \
     X(3072, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256, false) X(3072, 16, PRO_RMS_QUANT, EPI_CLS, 256, false)                  \

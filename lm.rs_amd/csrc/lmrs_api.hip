@@ -70,7 +70,7 @@ struct lmrs_ctx {
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
     // batched forward_layer (fill_kv_cache): device buffers for kPrefillTokens tokens, allocated on first use
-    float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr; int8_t* pf_xq = nullptr;
+    float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr, *pf_t = nullptr; int8_t* pf_xq = nullptr;
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
@@ -684,7 +684,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->g_step) hipGraphExecDestroy(c->g_step);
     if (c->g_layers) hipGraphExecDestroy(c->g_layers);
-    for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs}) if (q) (void)hipFree(q);
+    for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) hipHostFree(c->h_logits);
     if (c->h_tok) hipHostFree(c->h_tok);
@@ -757,15 +757,16 @@ extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, s
 // ------------------------------------------------------------------ batched forward_layer on the matrix cores
 constexpr int kPrefillTokens = 512;
 
-// Q8_0 Llama / Phi shapes on one GPU (the GEMM needs whole 16-row tiles and the per-token prologues their static shapes);
+// The model shapes the static per-token prologues exist for (Llama-3.2-1B/3B, Phi-3.5, Gemma-2-2B; Q8_0 and Q4_0) on one GPU;
 // everything else takes the token-by-token path below (same results).
 static bool prefill_batched_ok(const lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     if (getenv("LMRS_NO_BATCHED_PREFILL")) return false;
-    if (c->q4 || a.q_type != LMRS_Q8_0 || a.model_type == LMRS_GEMMA || c->world > 1 || c->comm || !c->g_layers) return false;
+    if ((a.q_type != LMRS_Q8_0 && a.q_type != LMRS_Q4_0) || c->world > 1 || c->comm || !c->g_layers) return false;
     if (!rows_prologue_supported((int)a.dim) || !rows_prologue_supported(c->att_dim) || !rows_prologue_supported((int)a.hidden_dim)) return false;
-    if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
-    return (c->att_dim + 2 * c->kv_dim) % 16 == 0 && c->kv_dim % 4 == 0;
+    if (a.model_type == LMRS_GEMMA) { if (a.head_size != 256 || a.dim != 2304) return false; }
+    else if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
+    return (c->att_dim + 2 * c->kv_dim) % 16 == 0 && c->kv_dim % 4 == 0 && a.dim % 16 == 0;
 }
 
 static int prefill_alloc(lmrs_ctx* c) {
@@ -779,19 +780,25 @@ static int prefill_alloc(lmrs_ctx* c) {
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_h), B * a.hidden_dim * 4));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_xq), B * wide));
     HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_xs), B * (wide / 128) * 4));
+    if (a.model_type == LMRS_GEMMA) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_t), B * a.dim * 4));
     return 0;
 }
 
-// forward_layer(sl = m) for every layer over tokens at positions p0 .. p0+m-1 whose embeddings sit in c->pf_x
+// forward_layer(sl = m) for every layer over tokens at positions p0 .. p0+m-1 whose embeddings sit in c->pf_x.
+// Gemma: the branch outputs go to pf_t and "x += rmsnorm(branch)" (transformer.rs:563-568, 643-650) is folded into the
+// per-token prologue of the next GEMM (mode 2), as in the decode path; the last one is applied at the end.
 static int prefill_layers(lmrs_ctx* c, int m, int p0) {
     const lmrs_args& a = c->args;
-    const int dim = (int)a.dim, hid = (int)a.hidden_dim, att = c->att_dim, kv = c->kv_dim;
+    const int dim = (int)a.dim, hid = (int)a.hidden_dim, att = c->att_dim, kv = c->kv_dim, q4 = c->q4;
+    const bool gemma = a.model_type == LMRS_GEMMA;
+    const float eps = a.rms_norm_eps;
     for (uint32_t l = 0; l < a.n_layers; ++l) {
         const DevLayer& L = c->layers[l];
         GemmArgs g{};
-        g.xq = c->pf_xq; g.xs = c->pf_xs; g.n_tok = m;
-        // rmsnorm + quantize | Wqkv | q, raw k, v rows -> cache                      (transformer.rs:409-431)
-        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, a.rms_norm_eps, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        g.xq = c->pf_xq; g.xs = c->pf_xs; g.n_tok = m; g.q4 = q4;
+        // [x += rmsnorm(previous ffn out)] rmsnorm + quantize | Wqkv | q, raw k, v rows -> cache      (transformer.rs:409-431)
+        if (gemma && l > 0) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, c->pf_t, c->layers[l - 1].rms_post_ffn, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, nullptr, nullptr, eps, gemma, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
         g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
         g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
         HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
@@ -800,21 +807,23 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         AttnArgs t{};
         t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
         t.n_heads = (int)a.n_heads; t.n_kv_heads = (int)a.n_kv_heads; t.head_size = (int)a.head_size; t.seq_len = (int)a.seq_len; t.layer = (int)l;
-        t.gemma = 0; t.st = c->st;
+        t.gemma = gemma; t.st = c->st;
         HIP_OK(launch_attention_rows(t, p0, m, c->stream));
-        // quantize | Wo | x += ...                                                      (:550-576)
-        HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, 0.f, 0, att, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.wo; g.ws = L.so; g.n = att; g.o = dim; g.out = c->pf_x;
-        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
-        // rmsnorm + quantize | W1, W3 | silu(gate) * up                                 (:578-624)
-        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, a.rms_norm_eps, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        // quantize | Wo | x += ... (Gemma: -> pf_t)                                     (:550-576)
+        HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, att, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.wo; g.ws = L.so; g.n = att; g.o = dim; g.out = gemma ? c->pf_t : c->pf_x;
+        HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream));
+        // [x += rmsnorm(attention out)] rmsnorm + quantize | W1, W3 | act(gate) * up  (:578-624)
+        if (gemma) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_pre_ffn, c->pf_t, L.rms_post_att, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, nullptr, nullptr, eps, 0, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
         g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * hid; g.out = c->pf_h;
-        HIP_OK(launch_gemm_q8(g, EPI_SWIGLU, c->stream));
-        // quantize | W2 | x += ...                                                      (:630-654)
-        HIP_OK(launch_rows_prologue(c->pf_h, nullptr, 0.f, 0, hid, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.w2; g.ws = L.s2; g.n = hid; g.o = dim; g.out = c->pf_x;
-        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
+        HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
+        // quantize | W2 | x += ... (Gemma: -> pf_t)                                     (:630-654)
+        HIP_OK(launch_rows_prologue(c->pf_h, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, hid, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.w2; g.ws = L.s2; g.n = hid; g.o = dim; g.out = gemma ? c->pf_t : c->pf_x;
+        HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream));
     }
+    if (gemma) HIP_OK(launch_rows_addnorm(c->pf_x, c->pf_t, c->layers[a.n_layers - 1].rms_post_ffn, eps, dim, m, c->stream));
     return 0;
 }
 
@@ -828,6 +837,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
         // (a later chunk only needs the K/V rows of the earlier ones, exactly as inside the reference's single call).
         if (prefill_alloc(c)) return -1;
         const size_t dim = c->args.dim;
+        if (set_state(c, curr_pos, 0, (int)curr_pos)) return -1;      // Gemma's window test sees curr_pos for every token of the call
         for (uint32_t i0 = 0; i0 < n; i0 += kPrefillTokens) {
             const int m = (int)std::min<uint32_t>(kPrefillTokens, n - i0);
             HIP_OK(hipMemcpyAsync(c->pf_x, embeddings + (size_t)i0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, c->stream));
@@ -870,7 +880,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     // prompt tokens except the last only have to leave their K/V rows behind, which is forward_layer over a batch - the
     // matrix-core path of fill_kv_cache, value for value what the per-token passes produce.
     size_t done = 0;
-    if (n_prompt >= 9 && prefill_batched_ok(c)) {
+    if (n_prompt >= 9 && prefill_batched_ok(c) && c->args.model_type != LMRS_GEMMA) {      // (Gemma scales its embeddings in the embed kernel)
         if (prefill_alloc(c)) return -1;
         const size_t m_total = n_prompt - 1;
         for (size_t i0 = 0; i0 < m_total; i0 += kPrefillTokens) {

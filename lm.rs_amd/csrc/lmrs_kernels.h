@@ -93,13 +93,15 @@ constexpr int kMaxArgmaxParts = 4096;
 struct GemmArgs {
     const void* wq; const float* ws;     // weights [o][n] int8 + scales [o][n/128]
     const int8_t* xq; const float* xs;   // activations [n_tok][n] int8 + scales [n_tok][n/128]
-    int n, o, n_tok;
+    int n, o, n_tok; int q4;             // q4: weights [o][n/2] packed nibbles, activations int8 (q - 8), de-interleaved per 8
     float* out;                          // STORE / RESID: [n_tok][o]; SWIGLU: [n_tok][o/2]; QKV: q [n_tok][att_dim]
     float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer, pos0;    // EPI_QKV
 };
 hipError_t launch_gemm_q8(const GemmArgs& a, int epi, hipStream_t s);
 bool rows_prologue_supported(int n);
-hipError_t launch_rows_prologue(const float* x, const float* rms_w, float eps, int add_unit, int n, int n_tok, int8_t* xq, float* xs, hipStream_t s);
+hipError_t launch_rows_prologue(float* x, const float* rms_w, const float* delta, const float* add_w, float eps, int add_unit, int mode, int q4,
+                                int n, int n_tok, int8_t* xq, float* xs, hipStream_t s);
+hipError_t launch_rows_addnorm(float* x, const float* delta, const float* w, float eps, int n, int n_tok, hipStream_t s);
 hipError_t launch_rope_rows(float* q, const float* k_raw, float* k_cache, const float* rope, int n_heads, int n_kv_heads, int hs, int seq_len,
                             int layer, int pos0, int n_tok, hipStream_t s);
 hipError_t launch_attention_rows(const AttnArgs& a, int pos0, int n_tok, hipStream_t s);

@@ -222,11 +222,15 @@ def test_matmul_q8_token_batch_on_matrix_cores(L, n, o, sl):
     assert_bit_equal(got, ref, f"gemm {n}x{o}, {sl} tokens")
 
 
-@pytest.mark.parametrize("cfg,n_tok,pos0", [("mini-llama", 70, 5), ("mini-llama3b", 33, 0), ("mini-phi", 140, 2), ("mini-llama-long", 600, 3)])
-def test_fill_kv_cache_batched_prefill(L, cfg, n_tok, pos0):
+@pytest.mark.parametrize("cfg,q,n_tok,pos0", [("mini-llama", S.Q8_0, 70, 5), ("mini-llama3b", S.Q8_0, 33, 0), ("mini-phi", S.Q8_0, 140, 2),
+                                              ("mini-llama-long", S.Q8_0, 600, 3), ("mini-llama", S.Q4_0, 70, 5), ("mini-gemma", S.Q8_0, 50, 3),
+                                              ("mini-gemma", S.Q4_0, 75, 0)])
+def test_fill_kv_cache_batched_prefill(L, cfg, q, n_tok, pos0):
     """forward_layer(sl = n) as GEMMs over the token batch (more than one 64-token block; 600 tokens: more than one 512-token chunk):
-    the mutated embeddings, and the decode steps that continue on the prefilled KV cache, are bit-identical to the CPU path."""
-    img = S.build_image(cfg, S.Q8_0, seed=21)
+    the mutated embeddings, and the decode steps that continue on the prefilled KV cache, are bit-identical to the CPU path.
+    Q4_0: packed weights unpacked into MFMA fragments, Q4 activations; Gemma: folded norm+add rows, GELU, soft-capped scores and
+    the window quirk of a batched call."""
+    img = S.build_image(cfg, q, seed=21)
     m = L.Transformer(img); orc = O.Oracle(img)
     toks = S.prompt_tokens(cfg, n_tok, 21)
     a = m.get_embeddings(toks); b = orc.get_embeddings(toks)

@@ -148,6 +148,20 @@ int lmrs_debug_timeline(lmrs_ctx* ctx, unsigned long long* out, int max_nodes, i
 /* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos`. */
 int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);
 
+/* ---- CLIP image tower of the multimodal models  (src/vision.rs) ---------------------------
+ * lmrs_vision_create   <- VisionTransformer::new(data) -> (VisionTransformer, usize)   vision.rs:99-243
+ *   `section` points at the vision section of an LMRS multimodal file (offset = *bytes_consumed of lmrs_create);
+ *   *bytes_consumed = size of the section (the processor section follows).  Q8_0, CLIP ViT-L/14-336 geometry.
+ * lmrs_vision_forward  <- VisionTransformer::forward(pixel_values, num_crops) -> (Vec<f32>, u32)   vision.rs:244-577
+ *   pixel_values: num_crops * 3 * image_size^2 floats, normalised and cut into patches as PHI3VProcessor::process
+ *   produces them; out: num_crops * 576 * dim floats (class token dropped); *new_shape = 576 * dim.
+ *   Projections run as int8 matrix-core GEMMs over all tokens of all crops; the f32x8 lane structure of the
+ *   reference's layernorm / matmul_rest sums (and the patch-embedding tail quirk) is reproduced: same values. */
+typedef struct lmrs_vision lmrs_vision;
+int lmrs_vision_create(const uint8_t* section, size_t len, int device, lmrs_vision** out, size_t* bytes_consumed);
+void lmrs_vision_destroy(lmrs_vision* v);
+int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, uint32_t num_crops, float* out, uint32_t* new_shape);
+
 #ifdef __cplusplus
 }
 #endif

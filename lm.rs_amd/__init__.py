@@ -29,6 +29,7 @@ EXPORTS = [
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
     "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
+    "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
 ]
 
 
@@ -85,6 +86,10 @@ def lib():
         L.lmrs_shard_uses_graph.argtypes = [vp]
         L.lmrs_group_create.argtypes = [vp, sz, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
         L.lmrs_group_forward.argtypes = [C.POINTER(vp), C.c_int, u32, u32, C.POINTER(f32p), C.POINTER(u32)]
+        L.lmrs_vision_create.argtypes = [vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.lmrs_vision_destroy.argtypes = [vp]
+        L.lmrs_vision_destroy.restype = None
+        L.lmrs_vision_forward.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -269,3 +274,32 @@ def expf(x, device=0):
     y = np.empty_like(x)
     _chk(lib().lmrs_op_expf(device, _p(y), _p(x), x.size))
     return y
+
+
+class VisionTransformer:
+    """lmrs::vision::VisionTransformer (src/vision.rs): the CLIP image tower of the multimodal models, on the device."""
+
+    def __init__(self, section: np.ndarray, device: int = 0):
+        sec = np.ascontiguousarray(section, np.uint8)
+        h = C.c_void_p(); used = C.c_size_t()
+        _chk(lib().lmrs_vision_create(sec.ctypes.data, sec.size, device, C.byref(h), C.byref(used)))
+        self._h, self.bytes_consumed = h, used.value
+
+    def forward(self, pixel_values: np.ndarray, num_crops: int) -> np.ndarray:
+        """-> float32 [num_crops, 576, dim] (vision.rs:244-577; the class token is dropped)."""
+        pv = np.ascontiguousarray(pixel_values, np.float32).reshape(-1)
+        if pv.size != num_crops * 3 * 336 * 336:
+            raise LmrsError("pixel_values must hold num_crops * 3 * 336 * 336 floats")
+        out = np.empty(num_crops * 576 * 1024, np.float32); ns = C.c_uint32()
+        _chk(lib().lmrs_vision_forward(self._h, pv.ctypes.data, num_crops, out.ctypes.data, C.byref(ns)))
+        return out.reshape(num_crops, 576, ns.value // 576)
+
+    def close(self):
+        if self._h:
+            lib().lmrs_vision_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1099,3 +1099,163 @@ extern "C" int lmrs_op_expf(int device, float* y, const float* x, size_t n) {
     HIP_OK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
+
+
+// ==================================================================================================
+// CLIP vision tower (reference src/vision.rs): VisionTransformer::new :99-243, forward :244-577.  Q8_0 sections.
+// ==================================================================================================
+struct VisLayer {
+    float *ln1 = nullptr, *ln1_b = nullptr, *ln2 = nullptr, *ln2_b = nullptr, *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    int8_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr; float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;
+};
+struct lmrs_vision {
+    int device = 0; hipStream_t stream = nullptr;
+    uint32_t dim = 0, hidden = 0, n_layers = 0, n_heads = 0, head_size = 0, patch = 0, image = 0, gs = 0; float eps = 0;
+    float *class_emb = nullptr, *patch_emb = nullptr, *pos_emb = nullptr, *pre_ln = nullptr, *pre_ln_b = nullptr;
+    std::vector<VisLayer> layers;
+    std::vector<void*> owned;
+    // work buffers, grown on demand
+    size_t cap_tok = 0;
+    float *pix = nullptr, *X = nullptr, *E = nullptr, *QKV = nullptr, *AO = nullptr, *H = nullptr, *scratch = nullptr, *xs = nullptr; int8_t* xq = nullptr;
+};
+
+namespace {
+template <class T> T* vis_dev(lmrs_vision* v, const void* src, size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) return nullptr;
+    v->owned.push_back(p);
+    if (src && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return static_cast<T*>(p);
+}
+uint32_t rd32(const uint8_t* p) { uint32_t x; memcpy(&x, p, 4); return x; }
+}  // namespace
+
+extern "C" void lmrs_vision_destroy(lmrs_vision* v) {
+    if (!v) return;
+    (void)hipSetDevice(v->device);
+    for (void* p : v->owned) (void)hipFree(p);
+    for (void* p : {(void*)v->pix, (void*)v->X, (void*)v->E, (void*)v->QKV, (void*)v->AO, (void*)v->H, (void*)v->scratch, (void*)v->xs, (void*)v->xq}) if (p) (void)hipFree(p);
+    if (v->stream) (void)hipStreamDestroy(v->stream);
+    delete v;
+}
+
+extern "C" int lmrs_vision_create(const uint8_t* sec, size_t len, int device, lmrs_vision** out, size_t* bytes_consumed) {
+    if (!sec || !out) return fail("NULL argument");
+    if (op_begin(device)) return -1;
+    if (len < 128) return fail("vision section shorter than its 128-byte header");
+    lmrs_vision* v = new lmrs_vision();
+    v->device = device;
+    v->dim = rd32(sec); v->hidden = rd32(sec + 4); v->n_layers = rd32(sec + 8); v->n_heads = rd32(sec + 12); v->head_size = rd32(sec + 16);
+    memcpy(&v->eps, sec + 20, 4); v->patch = rd32(sec + 24); v->image = rd32(sec + 28);
+    const uint8_t q_type = sec[32]; v->gs = rd32(sec + 33);
+    auto bad = [&](const char* m) { lmrs_vision_destroy(v); return fail(m); };
+    if (q_type != LMRS_Q8_0 || v->gs != 128) return bad("the vision tower is built for Q8_0 sections with group size 128");
+    // the reference hard-codes 577 positions (vision.rs:117); the kernels are built for CLIP ViT-L/14-336 geometry
+    if (v->dim != 1024 || v->head_size != 64 || v->n_heads * v->head_size != v->dim || v->patch == 0 || (v->image / v->patch) * (v->image / v->patch) != 576 ||
+        v->hidden % 256 || v->hidden != 4096 || v->n_layers < 2)
+        return bad("unsupported vision geometry (built for CLIP ViT-L/14-336: dim 1024, 16 heads of 64, 576 patches, hidden 4096)");
+    const size_t dim = v->dim, L = v->n_layers, hid = v->hidden, kdim = 3ull * v->patch * v->patch, G = dim / 128, GH = hid / 128;
+    const size_t need = 128 + 4 * (dim + dim * kdim + dim * 577 + 8 * L * dim + L * hid + L * dim + 2 * dim) + L * (4 * (dim * dim + dim * G * 4) + 2 * (dim * hid + dim * GH * 4));
+    if (len < need) return bad("vision section truncated");
+    HIP_OK(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    size_t off = 128;
+    auto f32v = [&](size_t count) { const uint8_t* p = sec + off; off += count * 4; return p; };
+    v->class_emb = vis_dev<float>(v, f32v(dim), dim * 4);
+    v->patch_emb = vis_dev<float>(v, f32v(dim * kdim), dim * kdim * 4);
+    v->pos_emb = vis_dev<float>(v, f32v(dim * 577), dim * 577 * 4);
+    v->layers.resize(L);
+    const uint8_t *ln1 = f32v(L * dim), *ln1b = f32v(L * dim), *ln2 = f32v(L * dim), *ln2b = f32v(L * dim);
+    // quantised tensors: per layer {int8 [rows*cols], f32 scales [rows*cols/128]}, then the bias block of all layers
+    struct QT { const uint8_t* q[64]; const uint8_t* s[64]; const uint8_t* bias; };
+    if (L > 64) return bad("too many vision layers");
+    auto quant = [&](size_t rows, size_t cols, size_t bias_len, QT& t) {
+        for (size_t l = 0; l < L; ++l) { t.q[l] = sec + off; off += rows * cols; t.s[l] = sec + off; off += rows * cols / 128 * 4; }
+        t.bias = sec + off; off += L * bias_len * 4;
+    };
+    QT tq, tk, tv, to, t1, t2;
+    quant(dim, dim, dim, tq); quant(dim, dim, dim, tk); quant(dim, dim, dim, tv); quant(dim, dim, dim, to);
+    quant(hid, dim, hid, t1); quant(dim, hid, dim, t2);
+    v->pre_ln = vis_dev<float>(v, f32v(dim), dim * 4);
+    v->pre_ln_b = vis_dev<float>(v, f32v(dim), dim * 4);
+    if (off != need) return bad("vision layout arithmetic");
+    for (size_t l = 0; l < L; ++l) {
+        VisLayer& Y = v->layers[l];
+        Y.ln1 = vis_dev<float>(v, ln1 + l * dim * 4, dim * 4); Y.ln1_b = vis_dev<float>(v, ln1b + l * dim * 4, dim * 4);
+        Y.ln2 = vis_dev<float>(v, ln2 + l * dim * 4, dim * 4); Y.ln2_b = vis_dev<float>(v, ln2b + l * dim * 4, dim * 4);
+        // q | k | v rows concatenated: one GEMM
+        Y.wqkv = vis_dev<int8_t>(v, nullptr, 3 * dim * dim); Y.sqkv = vis_dev<float>(v, nullptr, 3 * dim * G * 4); Y.bqkv = vis_dev<float>(v, nullptr, 3 * dim * 4);
+        if (!Y.wqkv || !Y.sqkv || !Y.bqkv) return bad("hipMalloc failed");
+        const QT* three[3] = {&tq, &tk, &tv};
+        for (int w = 0; w < 3; ++w) {
+            HIP_OK(hipMemcpy(Y.wqkv + (size_t)w * dim * dim, three[w]->q[l], dim * dim, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(Y.sqkv + (size_t)w * dim * G, three[w]->s[l], dim * G * 4, hipMemcpyHostToDevice));
+            HIP_OK(hipMemcpy(Y.bqkv + (size_t)w * dim, three[w]->bias + l * dim * 4, dim * 4, hipMemcpyHostToDevice));
+        }
+        Y.wo = vis_dev<int8_t>(v, to.q[l], dim * dim); Y.so = vis_dev<float>(v, to.s[l], dim * G * 4); Y.bo = vis_dev<float>(v, to.bias + l * dim * 4, dim * 4);
+        Y.w1 = vis_dev<int8_t>(v, t1.q[l], hid * dim); Y.s1 = vis_dev<float>(v, t1.s[l], hid * G * 4); Y.b1 = vis_dev<float>(v, t1.bias + l * hid * 4, hid * 4);
+        Y.w2 = vis_dev<int8_t>(v, t2.q[l], dim * hid); Y.s2 = vis_dev<float>(v, t2.s[l], dim * GH * 4); Y.b2 = vis_dev<float>(v, t2.bias + l * dim * 4, dim * 4);
+        if (!Y.ln1 || !Y.ln1_b || !Y.ln2 || !Y.ln2_b || !Y.wo || !Y.so || !Y.bo || !Y.w1 || !Y.s1 || !Y.b1 || !Y.w2 || !Y.s2 || !Y.b2) return bad("hipMalloc failed");
+    }
+    if (!v->class_emb || !v->patch_emb || !v->pos_emb || !v->pre_ln || !v->pre_ln_b) return bad("hipMalloc failed");
+    if (bytes_consumed) *bytes_consumed = off;
+    *out = v;
+    return 0;
+}
+
+static int vis_reserve(lmrs_vision* v, size_t n_tok, uint32_t num_crops) {
+    if (n_tok <= v->cap_tok) return 0;
+    for (void** p : {(void**)&v->pix, (void**)&v->X, (void**)&v->E, (void**)&v->QKV, (void**)&v->AO, (void**)&v->H, (void**)&v->scratch, (void**)&v->xs, (void**)&v->xq})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    v->cap_tok = 0;
+    const size_t dim = v->dim, hid = v->hidden;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->pix), (size_t)num_crops * 3 * v->image * v->image * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->X), n_tok * dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->E), n_tok * dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->QKV), n_tok * dim * 3 * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->AO), n_tok * dim * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->H), n_tok * hid * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->scratch), vis_attention_scratch_floats((int)num_crops, (int)v->n_heads, 577) * 4));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->xq), n_tok * hid));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&v->xs), n_tok * (hid / 128) * 4));
+    v->cap_tok = n_tok;
+    return 0;
+}
+
+// VisionTransformer::forward (vision.rs:244-577): pixel_values = num_crops * 3 * image^2 floats cut into patches
+// (processor.rs view_as_patches); out = num_crops * 576 * dim floats (CLS dropped); *new_shape = 576 * dim.
+extern "C" int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, uint32_t num_crops, float* out, uint32_t* new_shape) {
+    if (!v || !pixel_values || !out) return fail("NULL argument");
+    if (num_crops == 0 || num_crops > 64) return fail("num_crops out of range");
+    HIP_OK(hipSetDevice(v->device));
+    const int dim = (int)v->dim, hid = (int)v->hidden, T = 577, n_tok = (int)num_crops * T;
+    if (vis_reserve(v, (size_t)n_tok, num_crops)) return -1;
+    hipStream_t s = v->stream;
+    const size_t img = 3ull * v->image * v->image;
+    HIP_OK(hipMemcpyAsync(v->pix, pixel_values, (size_t)num_crops * img * 4, hipMemcpyHostToDevice, s));
+    VisPatchArgs pa{v->pix, v->patch_emb, v->class_emb, v->pos_emb, v->E, dim, 576, (int)(3 * v->patch * v->patch)};
+    HIP_OK(launch_vis_patch_embed(pa, (int)num_crops, s));
+    HIP_OK(launch_vis_layernorm(v->E, v->pre_ln, v->pre_ln_b, v->eps, dim, n_tok, v->X, nullptr, nullptr, s));     // input layernorm (:293-301)
+    for (uint32_t l = 0; l + 1 < v->n_layers; ++l) {                      // the penultimate layer's output is used (:303)
+        const VisLayer& Y = v->layers[l];
+        GemmArgs g{};
+        g.xq = v->xq; g.xs = v->xs; g.n_tok = n_tok;
+        HIP_OK(launch_vis_layernorm(v->X, Y.ln1, Y.ln1_b, v->eps, dim, n_tok, nullptr, v->xq, v->xs, s));
+        g.wq = Y.wqkv; g.ws = Y.sqkv; g.n = dim; g.o = 3 * dim; g.out = v->QKV; g.bias = Y.bqkv; g.att_dim = dim; g.qscale = sqrtf((float)v->head_size);
+        HIP_OK(launch_gemm_q8(g, EPI_VQKV, s));
+        HIP_OK(launch_vis_attention(v->QKV, v->AO, v->scratch, (int)num_crops, (int)v->n_heads, T, dim, s));
+        HIP_OK(launch_rows_prologue(v->AO, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, dim, n_tok, v->xq, v->xs, s));
+        g.wq = Y.wo; g.ws = Y.so; g.n = dim; g.o = dim; g.out = v->E; g.bias = Y.bo; g.resid = v->X;
+        HIP_OK(launch_gemm_q8(g, EPI_BIAS_RESID, s));
+        HIP_OK(launch_vis_layernorm(v->E, Y.ln2, Y.ln2_b, v->eps, dim, n_tok, nullptr, v->xq, v->xs, s));
+        g.wq = Y.w1; g.ws = Y.s1; g.n = dim; g.o = hid; g.out = v->H; g.bias = Y.b1; g.resid = nullptr;
+        HIP_OK(launch_gemm_q8(g, EPI_BIAS_QGELU, s));
+        HIP_OK(launch_rows_prologue(v->H, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, hid, n_tok, v->xq, v->xs, s));
+        g.wq = Y.w2; g.ws = Y.s2; g.n = hid; g.o = dim; g.out = v->X; g.bias = Y.b2; g.resid = v->E;
+        HIP_OK(launch_gemm_q8(g, EPI_BIAS_RESID, s));
+    }
+    for (uint32_t c = 0; c < num_crops; ++c)                               // drop the CLS embedding (:571-579)
+        HIP_OK(hipMemcpyAsync(out + (size_t)c * 576 * dim, v->X + ((size_t)c * T + 1) * dim, (size_t)576 * dim * 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (new_shape) *new_shape = 576u * (uint32_t)dim;
+    return 0;
+}

@@ -15,7 +15,9 @@ struct DevState {
 };
 
 enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3 };   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
-enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5 };
+enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5,
+                // CLIP tower (batched GEMM only): + bias with q / sqrt(head) | + bias + residual | + bias, QuickGELU
+                EPI_VQKV = 6, EPI_BIAS_RESID = 7, EPI_BIAS_QGELU = 8 };
 
 struct GemvArgs {
     // weights: o rows of n int8 (Q8_0) / n/2 bytes (Q4_0), row-major; scales o * (n/128) f32
@@ -96,6 +98,7 @@ struct GemmArgs {
     int n, o, n_tok; int q4;             // q4: weights [o][n/2] packed nibbles, activations int8 (q - 8), de-interleaved per 8
     float* out;                          // STORE / RESID: [n_tok][o]; SWIGLU: [n_tok][o/2]; QKV: q [n_tok][att_dim]
     float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer, pos0;    // EPI_QKV
+    const float* bias; const float* resid; float qscale;                         // CLIP epilogues: bias [o], residual [n_tok][o], sqrt(head_size)
 };
 hipError_t launch_gemm_q8(const GemmArgs& a, int epi, hipStream_t s);
 bool rows_prologue_supported(int n);
@@ -105,6 +108,14 @@ hipError_t launch_rows_addnorm(float* x, const float* delta, const float* w, flo
 hipError_t launch_rope_rows(float* q, const float* k_raw, float* k_cache, const float* rope, int n_heads, int n_kv_heads, int hs, int seq_len,
                             int layer, int pos0, int n_tok, hipStream_t s);
 hipError_t launch_attention_rows(const AttnArgs& a, int pos0, int n_tok, hipStream_t s);
+
+// ---- CLIP vision tower (lmrs_vision.inc; reference src/vision.rs:244-577), dim 1024 / 16 heads x 64 / 577 tokens per crop
+struct VisPatchArgs { const float* pixels; const float* kernel; const float* class_emb; const float* pos_emb; float* out; int dim, n_patches, kdim; };
+hipError_t launch_vis_patch_embed(const VisPatchArgs& a, int num_crops, hipStream_t s);
+// layernorm rows (functional.rs:80-114): out_f32 != null: f32 result; xq/xs != null: quantised result (Q8_0)
+hipError_t launch_vis_layernorm(const float* x, const float* w, const float* b, float eps, int dim, int n_tok, float* out_f32, int8_t* xq, float* xs, hipStream_t s);
+hipError_t launch_vis_attention(const float* qkv, float* out, float* scratch, int num_crops, int n_heads, int T, int dim, hipStream_t s);
+size_t vis_attention_scratch_floats(int num_crops, int n_heads, int T);
 
 // ---- fused attention block (lmrs_fused.inc): qkv -> attention -> wo of one layer in one launch
 struct FusedAttnArgs {

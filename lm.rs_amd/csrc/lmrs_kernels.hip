@@ -1332,6 +1332,7 @@ hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st) {
 }
 
 #include "lmrs_prefill.inc"
+#include "lmrs_vision.inc"
 #include "lmrs_fused.inc"
 
 }  // namespace lmrs

@@ -170,3 +170,38 @@ def threads() -> int:
 
 def set_threads(n: int):
     lib().lmrs_ref_set_threads(n)
+
+
+class VisionOracle:
+    """CPU restatement of the reference's CLIP tower (src/vision.rs), Q8_0."""
+
+    def __init__(self, section: np.ndarray):
+        L = lib()
+        L.lmrs_ref_vision_create.restype = C.c_int
+        L.lmrs_ref_vision_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.lmrs_ref_vision_forward.restype = C.c_int
+        L.lmrs_ref_vision_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.lmrs_ref_vision_destroy.argtypes = [C.c_void_p]
+        L.lmrs_ref_vision_args.argtypes = [C.c_void_p, C.c_void_p]
+        sec = np.ascontiguousarray(section, np.uint8)
+        h = C.c_void_p(); used = C.c_size_t()
+        if L.lmrs_ref_vision_create(sec.ctypes.data, sec.size, C.byref(h), C.byref(used)):
+            raise RuntimeError(L.lmrs_ref_last_error().decode())
+        self._h, self.bytes_consumed = h, used.value
+        a = np.zeros(8, np.uint32); L.lmrs_ref_vision_args(h, a.ctypes.data)
+        self.dim, self.n_layers, self.image_size, self.patch_size = int(a[0]), int(a[2]), int(a[6]), int(a[5])
+
+    def forward(self, pixel_values: np.ndarray, num_crops: int) -> np.ndarray:
+        pv = np.ascontiguousarray(pixel_values, np.float32).reshape(-1)
+        n = (self.image_size // self.patch_size) ** 2
+        out = np.zeros(num_crops * n * self.dim, np.float32); ns = C.c_uint32()
+        if lib().lmrs_ref_vision_forward(self._h, pv.ctypes.data, num_crops, out.ctypes.data, C.byref(ns)):
+            raise RuntimeError(lib().lmrs_ref_last_error().decode())
+        assert ns.value == n * self.dim
+        return out.reshape(num_crops, n, self.dim)
+
+    def __del__(self):
+        try:
+            lib().lmrs_ref_vision_destroy(self._h)
+        except Exception:
+            pass

@@ -382,3 +382,19 @@ def test_errors(L):
         m.forward(0, m.args.seq_len)
     with pytest.raises(L.LmrsError):
         m.generate_greedy(np.zeros(0, np.uint32), 4)
+
+
+# ------------------------------------------------------------------ CLIP image tower (BASELINE configs[4])
+@pytest.mark.parametrize("n_layers,num_crops", [(2, 1), (3, 2)])
+def test_vision_tower_matches_the_cpu_path(L, n_layers, num_crops):
+    """VisionTransformer::forward (vision.rs:244-577) at the real CLIP ViT-L/14-336 geometry (the reference hard-codes 577
+    positions), a few layers deep: patch embedding with the matmul_rest tail quirk, f32x8-structured layernorm and attention
+    sums, Q8_0 projections as int8 matrix-core GEMMs with bias / QuickGELU / residual epilogues - bit-equal to the CPU path."""
+    from tools import synth_vision as V
+    cfg = V.VisionCfg(n_layers=n_layers)
+    sec = V.build_vision_section(cfg, seed=5 + n_layers)
+    dev = L.VisionTransformer(sec); orc = O.VisionOracle(sec)
+    assert dev.bytes_consumed == orc.bytes_consumed == sec.size
+    pv = V.pixel_values(cfg, num_crops, seed=3)
+    got = dev.forward(pv, num_crops); ref = orc.forward(pv, num_crops)
+    assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"vision tower, {n_layers - 1} layer(s), {num_crops} crop(s)")

@@ -162,6 +162,25 @@ int lmrs_vision_create(const uint8_t* section, size_t len, int device, lmrs_visi
 void lmrs_vision_destroy(lmrs_vision* v);
 int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, uint32_t num_crops, float* out, uint32_t* new_shape);
 
+/* --------------------------------------------------------------------------------------------------------------------------
+ * Image projector of the multimodal models (reference src/processor.rs, struct PHI3VProcessor).  Q8_0 sections.
+ *
+ * lmrs_processor_create   <- PHI3VProcessor::new(data) -> PHI3VProcessor              processor.rs:168-232
+ *     section = the bytes that follow the vision tower's section in the model file (128-byte header: hidden_dim, text_dim,
+ *     q_type, group_size; glb_GN, sub_GN, the two projections, their biases).
+ * lmrs_processor_forward  <- PHI3VProcessor::forward(out_patches, new_shape, patch_side, w_crop, h_crop) -> (Vec<f32>, u32)
+ *                                                                                       processor.rs:234-342
+ *     out_patches = lmrs_vision_forward's output (global crop first), total_floats floats; the HD transform
+ *     (reshape_hd_patches_2x2merge :377-418, add_image_newline :480-484), the separators and the two-layer tanh-GELU MLP;
+ *     out receives n_embeds * text_dim floats, n_embeds = (h_crop*12)*(w_crop*12+1) + 12*13 + 1.
+ * lmrs_processor_destroy  <- Drop
+ */
+typedef struct lmrs_processor lmrs_processor;
+int lmrs_processor_create(const uint8_t* section, size_t len, int device, lmrs_processor** out, size_t* bytes_consumed);
+void lmrs_processor_destroy(lmrs_processor* p);
+int lmrs_processor_forward(lmrs_processor* p, const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t patch_side,
+                           uint32_t w_crop, uint32_t h_crop, float* out, uint32_t* n_embeds);
+
 #ifdef __cplusplus
 }
 #endif

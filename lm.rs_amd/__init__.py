@@ -30,6 +30,7 @@ EXPORTS = [
     "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
+    "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward",
 ]
 
 
@@ -90,6 +91,10 @@ def lib():
         L.lmrs_vision_destroy.argtypes = [vp]
         L.lmrs_vision_destroy.restype = None
         L.lmrs_vision_forward.argtypes = [vp, vp, u32, vp, C.POINTER(u32)]
+        L.lmrs_processor_create.argtypes = [vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.lmrs_processor_destroy.argtypes = [vp]
+        L.lmrs_processor_destroy.restype = None
+        L.lmrs_processor_forward.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -297,6 +302,35 @@ class VisionTransformer:
     def close(self):
         if self._h:
             lib().lmrs_vision_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PHI3VProcessor:
+    """lmrs::processor::PHI3VProcessor (src/processor.rs:168-342): HD transform + two-layer projector, on the device."""
+
+    def __init__(self, section: np.ndarray, device: int = 0):
+        sec = np.ascontiguousarray(section, np.uint8)
+        h = C.c_void_p(); used = C.c_size_t()
+        _chk(lib().lmrs_processor_create(sec.ctypes.data, sec.size, device, C.byref(h), C.byref(used)))
+        self._h, self.bytes_consumed = h, used.value
+        self.text_dim = int(np.frombuffer(sec[4:8].tobytes(), np.uint32)[0])
+
+    def forward(self, out_patches: np.ndarray, new_shape: int, patch_side: int, w_crop: int, h_crop: int) -> np.ndarray:
+        """-> float32 [num_embeds, text_dim] (processor.rs:234-342)."""
+        op = np.ascontiguousarray(out_patches, np.float32).reshape(-1)
+        ne = (h_crop * patch_side) * (w_crop * patch_side + 1) + patch_side * (patch_side + 1) + 1
+        out = np.empty(ne * self.text_dim, np.float32); n = C.c_uint32()
+        _chk(lib().lmrs_processor_forward(self._h, op.ctypes.data, op.size, new_shape, patch_side, w_crop, h_crop, out.ctypes.data, C.byref(n)))
+        return out[: n.value * self.text_dim].reshape(n.value, self.text_dim)
+
+    def close(self):
+        if self._h:
+            lib().lmrs_processor_destroy(self._h); self._h = None
 
     def __del__(self):
         try:

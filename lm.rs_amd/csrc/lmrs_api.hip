@@ -1259,3 +1259,120 @@ extern "C" int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, ui
     if (new_shape) *new_shape = 576u * (uint32_t)dim;
     return 0;
 }
+
+
+// ==================================================================================================
+// PHI3VProcessor (reference src/processor.rs): new :168-232, forward :234-342.  Q8_0 sections.
+// The HD transform (reshape_hd_patches_2x2merge :377-418, add_image_newline :480-484) is data movement and runs on the host
+// where the tower's output already is; the projector MLP runs as two int8 matrix-core GEMMs over all embeddings.
+// ==================================================================================================
+struct lmrs_processor {
+    int device = 0; hipStream_t stream = nullptr;
+    uint32_t hidden = 0, text = 0;
+    std::vector<float> glb_gn, sub_gn;
+    int8_t *p0 = nullptr, *p1 = nullptr; float *s0 = nullptr, *s1 = nullptr, *b0 = nullptr, *b1 = nullptr;
+    size_t cap = 0; float *emb = nullptr, *hid = nullptr, *outd = nullptr, *xs = nullptr; int8_t* xq = nullptr;
+};
+
+extern "C" void lmrs_processor_destroy(lmrs_processor* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (void* q : {(void*)p->p0, (void*)p->p1, (void*)p->s0, (void*)p->s1, (void*)p->b0, (void*)p->b1, (void*)p->emb, (void*)p->hid, (void*)p->outd, (void*)p->xs, (void*)p->xq})
+        if (q) (void)hipFree(q);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" int lmrs_processor_create(const uint8_t* sec, size_t len, int device, lmrs_processor** out, size_t* bytes_consumed) {
+    if (!sec || !out) return fail("NULL argument");
+    if (op_begin(device)) return -1;
+    if (len < 128) return fail("processor section shorter than its 128-byte header");
+    lmrs_processor* p = new lmrs_processor();
+    p->device = device; p->hidden = rd32(sec); p->text = rd32(sec + 4);
+    const uint8_t q_type = sec[8]; const uint32_t gs = rd32(sec + 9);
+    auto bad = [&](const char* m) { lmrs_processor_destroy(p); return fail(m); };
+    if (q_type != LMRS_Q8_0 || gs != 128) return bad("the image projector is built for Q8_0 sections with group size 128");
+    // reshape_hd_patches_2x2merge hard-codes C = 1024 (processor.rs:378): hidden_dim = 4 * 1024
+    if (p->hidden != 4096 || !rows_prologue_supported((int)p->text) || p->text % 16) return bad("unsupported projector geometry (4096 -> text_dim in {2048, 3072})");
+    const size_t H = p->hidden, Tt = p->text;
+    const size_t need = 128 + 4 * (2 * H + 2 * Tt) + (Tt * H + Tt * H / 128 * 4) + (Tt * Tt + Tt * Tt / 128 * 4);
+    if (len < need) return bad("processor section truncated");
+    HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    size_t off = 128;
+    p->glb_gn.assign(reinterpret_cast<const float*>(sec + off), reinterpret_cast<const float*>(sec + off) + H); off += H * 4;
+    p->sub_gn.assign(reinterpret_cast<const float*>(sec + off), reinterpret_cast<const float*>(sec + off) + H); off += H * 4;
+    auto up = [&](void** dst, size_t bytes) { if (hipMalloc(dst, bytes) != hipSuccess) return false; const bool ok = hipMemcpy(*dst, sec + off, bytes, hipMemcpyHostToDevice) == hipSuccess; off += bytes; return ok; };
+    if (!up(reinterpret_cast<void**>(&p->p0), Tt * H) || !up(reinterpret_cast<void**>(&p->s0), Tt * H / 128 * 4) || !up(reinterpret_cast<void**>(&p->p1), Tt * Tt) ||
+        !up(reinterpret_cast<void**>(&p->s1), Tt * Tt / 128 * 4) || !up(reinterpret_cast<void**>(&p->b0), Tt * 4) || !up(reinterpret_cast<void**>(&p->b1), Tt * 4))
+        return bad("hipMalloc / upload failed");
+    if (bytes_consumed) *bytes_consumed = off;
+    *out = p;
+    return 0;
+}
+
+// reshape_hd_patches_2x2merge (processor.rs:377-418) followed by add_image_newline (:480-484): rows of 4 * 1024 floats
+static void hd_merge_with_newlines(const float* feat, size_t n_floats, size_t h_crop, size_t w_crop, const float* sep, std::vector<float>& res) {
+    const size_t C = 1024, H = 24, Lp = H * H, out_c = 4 * C;
+    const size_t n = n_floats / (Lp * C), num_images = n / (h_crop * w_crop), out_h = h_crop * H / 2, out_w = w_crop * H / 2;
+    std::vector<float> merged(num_images * out_h * out_w * out_c);
+    for (size_t img = 0; img < num_images; ++img)
+        for (size_t hc = 0; hc < h_crop; ++hc)
+            for (size_t wc = 0; wc < w_crop; ++wc) {
+                const size_t patch_idx = img * h_crop * w_crop + hc * w_crop + wc;
+                for (size_t i = 0; i < H / 2; ++i)
+                    for (size_t j = 0; j < H / 2; ++j) {
+                        float* dst = merged.data() + ((img * out_h + hc * H / 2 + i) * out_w + wc * H / 2 + j) * out_c;
+                        for (size_t di = 0; di < 2; ++di)
+                            for (size_t dj = 0; dj < 2; ++dj)
+                                memcpy(dst + (di * 2 + dj) * C, feat + patch_idx * Lp * C + ((i * 2 + di) * H + (j * 2 + dj)) * C, C * 4);
+                    }
+            }
+    const size_t total = num_images * out_h * out_w;
+    res.clear(); res.reserve((total + out_h) * out_c);
+    size_t src = 0;
+    for (size_t i = 0; i < out_h; ++i) {                                       // a separator after every row of out_w embeddings
+        res.insert(res.end(), merged.begin() + src * out_c, merged.begin() + (src + out_w) * out_c); src += out_w;
+        res.insert(res.end(), sep, sep + out_c);
+    }
+    res.insert(res.end(), merged.begin() + src * out_c, merged.begin() + total * out_c);
+}
+
+// PHI3VProcessor::forward (processor.rs:234-342).  out_patches: the tower's output (total_floats floats: the global crop first,
+// new_shape floats, then the h_crop x w_crop sub-images); out: num_embeds * text_dim floats; *n_embeds = number of embeddings.
+extern "C" int lmrs_processor_forward(lmrs_processor* p, const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t patch_side,
+                                      uint32_t w_crop, uint32_t h_crop, float* out, uint32_t* n_embeds) {
+    if (!p || !out_patches || !out) return fail("NULL argument");
+    if (patch_side != 12 || new_shape != 576u * 1024u || w_crop == 0 || h_crop == 0 || (size_t)total_floats != (size_t)new_shape * (1 + (size_t)w_crop * h_crop))
+        return fail("processor: out_patches must hold the global crop and h_crop * w_crop sub-images of 576 x 1024 floats (patch_side 12)");
+    HIP_OK(hipSetDevice(p->device));
+    const size_t H = p->hidden, Tt = p->text;
+    std::vector<float> glob, sub, emb;
+    hd_merge_with_newlines(out_patches, new_shape, 1, 1, p->sub_gn.data(), glob);
+    hd_merge_with_newlines(out_patches + new_shape, (size_t)total_floats - new_shape, h_crop, w_crop, p->sub_gn.data(), sub);
+    emb.reserve(sub.size() + H + glob.size());
+    emb.insert(emb.end(), sub.begin(), sub.end()); emb.insert(emb.end(), p->glb_gn.begin(), p->glb_gn.end()); emb.insert(emb.end(), glob.begin(), glob.end());
+    const size_t ne = emb.size() / H;
+    if (ne != (size_t)(h_crop * patch_side) * (w_crop * patch_side + 1) + (size_t)patch_side * (patch_side + 1) + 1) return fail("processor: embedding count");
+    if (ne > p->cap) {
+        for (void** q : {(void**)&p->emb, (void**)&p->hid, (void**)&p->outd, (void**)&p->xs, (void**)&p->xq}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+        p->cap = 0;
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&p->emb), ne * H * 4)); HIP_OK(hipMalloc(reinterpret_cast<void**>(&p->hid), ne * Tt * 4));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&p->outd), ne * Tt * 4)); HIP_OK(hipMalloc(reinterpret_cast<void**>(&p->xq), ne * H));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&p->xs), ne * (H / 128) * 4));
+        p->cap = ne;
+    }
+    hipStream_t s = p->stream;
+    HIP_OK(hipMemcpyAsync(p->emb, emb.data(), ne * H * 4, hipMemcpyHostToDevice, s));
+    GemmArgs g{};
+    g.xq = p->xq; g.xs = p->xs; g.n_tok = (int)ne;
+    HIP_OK(launch_rows_prologue(p->emb, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, (int)H, (int)ne, p->xq, p->xs, s));
+    g.wq = p->p0; g.ws = p->s0; g.n = (int)H; g.o = (int)Tt; g.out = p->hid; g.bias = p->b0;
+    HIP_OK(launch_gemm_q8(g, EPI_BIAS_GELU, s));
+    HIP_OK(launch_rows_prologue(p->hid, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, (int)Tt, (int)ne, p->xq, p->xs, s));
+    g.wq = p->p1; g.ws = p->s1; g.n = (int)Tt; g.o = (int)Tt; g.out = p->outd; g.bias = p->b1;
+    HIP_OK(launch_gemm_q8(g, EPI_BIAS, s));
+    HIP_OK(hipMemcpyAsync(out, p->outd, ne * Tt * 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (n_embeds) *n_embeds = (uint32_t)ne;
+    return 0;
+}

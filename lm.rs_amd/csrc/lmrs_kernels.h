@@ -17,7 +17,9 @@ struct DevState {
 enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3 };   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
 enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5,
                 // CLIP tower (batched GEMM only): + bias with q / sqrt(head) | + bias + residual | + bias, QuickGELU
-                EPI_VQKV = 6, EPI_BIAS_RESID = 7, EPI_BIAS_QGELU = 8 };
+                EPI_VQKV = 6, EPI_BIAS_RESID = 7, EPI_BIAS_QGELU = 8,
+                // image projector (processor.rs:234-342): + bias, tanh-GELU | + bias
+                EPI_BIAS_GELU = 9, EPI_BIAS = 10 };
 
 struct GemvArgs {
     // weights: o rows of n int8 (Q8_0) / n/2 bytes (Q4_0), row-major; scales o * (n/128) f32

@@ -256,3 +256,47 @@ class NumpyModel:
             for d_ in range(self.dim):
                 v = F(logits[d_] / F(30.0)); v = F(_libm.tanh(float(v))); logits[d_] = F(v * F(30.0))
         return logits
+
+
+# ------------------------------------------------------------------ image projector (reference src/processor.rs:234-342)
+def hd_transform(feats, h_crop, w_crop, sep):
+    """reshape_hd_patches_2x2merge (:377-418) + add_image_newline (:480-484), as one reshape/transpose: [n, 576, C] ->
+    [h_crop*12 * (w_crop*12 + 1), 4C]."""
+    n, L, Cc = feats.shape
+    H = int(math.isqrt(L)); ni = n // (h_crop * w_crop)
+    assert ni == 1
+    t = feats.reshape(ni, h_crop, w_crop, H // 2, 2, H // 2, 2, Cc)           # img, hc, wc, i, di, j, dj, C
+    t = t.transpose(0, 1, 3, 2, 5, 4, 6, 7).reshape(ni * h_crop * (H // 2), w_crop * (H // 2), 4 * Cc)
+    nl = np.broadcast_to(sep.reshape(1, 1, -1), (t.shape[0], 1, 4 * Cc))
+    return np.concatenate([t, nl], axis=1).reshape(-1, 4 * Cc)
+
+
+def gelu_tanh(h):
+    cube = (F(0.044715) * h).astype(F); cube = (cube * h).astype(F); cube = (cube * h).astype(F)
+    inner = (h + cube).astype(F).astype(np.float64) * 0.7978845608028654
+    th = np.array([_libm.tanh(float(v)) for v in inner], np.float64).astype(F)
+    return (h * (F(0.5) * (F(1.0) + th).astype(F)).astype(F)).astype(F)
+
+
+def processor_forward(section, feats, w_crop, h_crop, rows=None):
+    hidden, text = struct.unpack_from("II", section, 0)
+    gs = struct.unpack_from("I", section, 9)[0]
+    off = 128
+    def take(dt, cnt):
+        nonlocal off
+        a = np.frombuffer(section, dt, cnt, off); off += a.nbytes
+        return a
+    glb, sub = take(F, hidden), take(F, hidden)
+    p0, s0 = take(np.int8, text * hidden), take(F, text * hidden // gs)
+    p1, s1 = take(np.int8, text * text), take(F, text * text // gs)
+    b0, b1 = take(F, text), take(F, text)
+    emb = np.concatenate([hd_transform(feats[1:], h_crop, w_crop, sub), glb.reshape(1, -1), hd_transform(feats[:1], 1, 1, sub)])
+    pick = range(emb.shape[0]) if rows is None else rows
+    out = {}
+    for r in pick:
+        q, sc = quantize_q8(emb[r], gs)
+        h = (matmul_q(q, sc, p0, s0, hidden, text, gs, False) + b0).astype(F)
+        h = gelu_tanh(h)
+        q, sc = quantize_q8(h, gs)
+        out[r] = (matmul_q(q, sc, p1, s1, text, text, gs, False) + b1).astype(F)
+    return emb.shape[0], out

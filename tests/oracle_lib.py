@@ -205,3 +205,37 @@ class VisionOracle:
             lib().lmrs_ref_vision_destroy(self._h)
         except Exception:
             pass
+
+
+class ProcessorOracle:
+    """CPU restatement of the reference's PHI3VProcessor (src/processor.rs:168-342), Q8_0."""
+
+    def __init__(self, section: np.ndarray):
+        L = lib()
+        L.lmrs_ref_processor_create.restype = C.c_int
+        L.lmrs_ref_processor_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.lmrs_ref_processor_forward.restype = C.c_int
+        L.lmrs_ref_processor_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_void_p, C.POINTER(C.c_uint32)]
+        L.lmrs_ref_processor_destroy.argtypes = [C.c_void_p]
+        sec = np.ascontiguousarray(section, np.uint8)
+        h = C.c_void_p(); used = C.c_size_t()
+        if L.lmrs_ref_processor_create(sec.ctypes.data, sec.size, C.byref(h), C.byref(used)):
+            raise RuntimeError(L.lmrs_ref_last_error().decode())
+        self._h, self.bytes_consumed = h, used.value
+        self.text_dim = int(np.frombuffer(sec[4:8].tobytes(), np.uint32)[0])
+
+    def forward(self, out_patches: np.ndarray, new_shape: int, patch_side: int, w_crop: int, h_crop: int) -> np.ndarray:
+        op = np.ascontiguousarray(out_patches, np.float32).reshape(-1)
+        ne = (h_crop * patch_side) * (w_crop * patch_side + 1) + patch_side * (patch_side + 1) + 1
+        out = np.zeros(ne * self.text_dim, np.float32); n = C.c_uint32()
+        if lib().lmrs_ref_processor_forward(self._h, op.ctypes.data, op.size, new_shape, patch_side, w_crop, h_crop, out.ctypes.data, C.byref(n)):
+            raise RuntimeError(lib().lmrs_ref_last_error().decode())
+        assert n.value == ne
+        return out.reshape(ne, self.text_dim)
+
+    def __del__(self):
+        try:
+            lib().lmrs_ref_processor_destroy(self._h)
+        except Exception:
+            pass

@@ -398,3 +398,30 @@ def test_vision_tower_matches_the_cpu_path(L, n_layers, num_crops):
     pv = V.pixel_values(cfg, num_crops, seed=3)
     got = dev.forward(pv, num_crops); ref = orc.forward(pv, num_crops)
     assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"vision tower, {n_layers - 1} layer(s), {num_crops} crop(s)")
+
+
+@pytest.mark.parametrize("w_crop,h_crop", [(1, 1), (2, 1)])
+def test_image_projector_matches_the_cpu_path(L, w_crop, h_crop):
+    """PHI3VProcessor::forward (processor.rs:234-342): the 2x2 HD merge, the row separators (sub_GN), glb_GN between the
+    sub-image and global features, then quantise -> proj0 + bias -> tanh-GELU (f64 tanh) -> quantise -> proj1 + bias for every
+    embedding, as two int8 matrix-core GEMMs - bit-equal to the CPU path."""
+    from tools import synth_vision as V
+    sec = V.build_processor_section(seed=11)
+    dev = L.PHI3VProcessor(sec); orc = O.ProcessorOracle(sec)
+    assert dev.bytes_consumed == orc.bytes_consumed == sec.size
+    n_crops = 1 + w_crop * h_crop
+    rng = np.random.default_rng(17 + w_crop)
+    feats = (rng.standard_normal((n_crops, 576, 1024)) * 1.5).astype(np.float32)
+    got = dev.forward(feats, 576 * 1024, 12, w_crop, h_crop); ref = orc.forward(feats, 576 * 1024, 12, w_crop, h_crop)
+    assert got.shape == ref.shape == ((h_crop * 12) * (w_crop * 12 + 1) + 12 * 13 + 1, 3072)
+    assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"image projector, {w_crop}x{h_crop} sub-images")
+
+
+def test_image_projector_rejects_bad_geometry(L):
+    from tools import synth_vision as V
+    sec = V.build_processor_section(seed=11)
+    dev = L.PHI3VProcessor(sec)
+    with pytest.raises(L.LmrsError):
+        dev.forward(np.zeros((2, 576, 1024), np.float32), 576 * 1024, 12, 2, 1)      # 3 crops promised, 2 given
+    with pytest.raises(L.LmrsError):
+        L.PHI3VProcessor(sec[: sec.size // 2])

@@ -40,3 +40,21 @@ def test_ops_match_numpy():
     for unit in (False, True):
         a = O.rmsnorm(x, w, 1e-5, unit); b = NR.rmsnorm(x, w, 1e-5, unit)
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_image_projector_oracle_matches_numpy_transcription():
+    """processor.rs:234-342: the C restatement against a reshape/transpose statement of the HD transform and the numpy Q8 ops,
+    on rows that cover the sub-image body, a row separator, glb_GN, the global crop and its last separator."""
+    from tools import synth_vision as V
+    sec = V.build_processor_section(seed=11)
+    orc = O.ProcessorOracle(sec)
+    rng = np.random.default_rng(4)
+    w_crop, h_crop = 2, 1
+    feats = (rng.standard_normal((1 + w_crop * h_crop, 576, 1024)) * 1.5).astype(np.float32)
+    ref = orc.forward(feats, 576 * 1024, 12, w_crop, h_crop)
+    n_sub = 12 * h_crop * (12 * w_crop + 1)
+    rows = [0, 23, 24, 25, 12 * w_crop * 7 + 7 + 13, n_sub - 1, n_sub, n_sub + 1, n_sub + 13, n_sub + 14, ref.shape[0] - 2, ref.shape[0] - 1]
+    ne, got = NR.processor_forward(sec.tobytes(), feats, w_crop, h_crop, rows)
+    assert ne == ref.shape[0]
+    for r in rows:
+        assert (got[r].view(np.uint32) == ref[r].view(np.uint32)).all(), f"embedding {r}: {np.flatnonzero(got[r] != ref[r])[:5]}"

@@ -71,3 +71,23 @@ def pixel_values(cfg: VisionCfg, num_crops: int, seed: int = 7) -> np.ndarray:
     [num_crops][576 patches][3 * 14 * 14] f32."""
     n = (cfg.image_size // cfg.patch_size) ** 2
     return np.random.default_rng(seed).standard_normal((num_crops, n, 3 * cfg.patch_size ** 2), dtype=np.float32)
+
+
+def build_processor_section(hidden_dim: int = 4096, text_dim: int = 3072, seed: int = 123, gs: int = 128) -> np.ndarray:
+    """Processor section (export.py:155-170, read back by src/processor.rs:168-232): 13-byte header padded to 128, glb_GN,
+    sub_GN, the two projector matrices (Q8_0), their biases."""
+    rng = np.random.default_rng(seed)
+    h = struct.pack("II", hidden_dim, text_dim) + struct.pack("B", Q8_0) + struct.pack("I", gs)
+    assert len(h) == 13
+    parts = [np.frombuffer(h + b"\0" * (128 - len(h)), np.uint8)]
+
+    def f32(shape, sigma):
+        return (sigma * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+
+    parts.append(f32((hidden_dim,), 0.5).view(np.uint8))                        # glb_GN
+    parts.append(f32((hidden_dim,), 0.5).view(np.uint8))                        # sub_GN
+    for shape, sigma in (((text_dim, hidden_dim), 0.02), ((text_dim, text_dim), 0.02)):
+        q, s = quantize_q80(f32(shape, sigma), gs)
+        parts.append(q.view(np.uint8).reshape(-1)); parts.append(np.ascontiguousarray(s, np.float32).reshape(-1).view(np.uint8))
+    parts.append(f32((text_dim,), 0.05).view(np.uint8)); parts.append(f32((text_dim,), 0.05).view(np.uint8))
+    return np.concatenate(parts)

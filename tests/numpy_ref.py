@@ -300,3 +300,129 @@ def processor_forward(section, feats, w_crop, h_crop, rows=None):
         q, sc = quantize_q8(h, gs)
         out[r] = (matmul_q(q, sc, p1, s1, text, text, gs, False) + b1).astype(F)
     return emb.shape[0], out
+
+
+# ------------------------------------------------------------------ CLIP tower (reference src/vision.rs:99-577), Q8_0
+def _expf_arr(a):
+    f = _libm.expf
+    return np.array([f(float(v)) for v in a.reshape(-1)], F).reshape(a.shape)
+
+
+def lane_dot(xa, wa):
+    """matmul_rest / matmul inner loop (functional.rs:252-280) for n % 8 == 0: xa [..., n] . wa [..., n] with the f32x8
+    accumulator (8 lane sums over chunks ascending) and wide's reduce_add; broadcasts over leading axes."""
+    n = xa.shape[-1]
+    acc = None
+    for j in range(n // 8):
+        p = (wa[..., j * 8:j * 8 + 8] * xa[..., j * 8:j * 8 + 8]).astype(F)
+        acc = p if acc is None else (acc + p).astype(F)          # 0 + p == p exactly
+    a = [acc[..., i] for i in range(8)]
+    return ((a[0] + a[4]).astype(F) + (a[2] + a[6]).astype(F)).astype(F) + ((a[1] + a[5]).astype(F) + (a[3] + a[7]).astype(F)).astype(F)
+
+
+def layernorm_rows(x, w, b, eps):
+    """functional.rs:80-114 for every row of x [T, n]."""
+    T, n = x.shape
+    xs = x.reshape(T, n // 8, 8)
+    m = np.zeros((T, 8), F)
+    for j in range(n // 8):
+        m = (m + xs[:, j]).astype(F)
+    mean = (reduce_add8(m.T) / F(n)).astype(F)
+    v = np.zeros((T, 8), F)
+    for j in range(n // 8):
+        d = (xs[:, j] - mean[:, None]).astype(F)
+        v = (v + (d * d).astype(F)).astype(F)
+    var = ((reduce_add8(v.T) / F(n)).astype(F) + F(eps)).astype(F)
+    inv = (F(1.0) / np.sqrt(var).astype(F)).astype(F)
+    nrm = ((x - mean[:, None]).astype(F) * inv[:, None]).astype(F)
+    return ((nrm * w[None, :]).astype(F) + b[None, :]).astype(F)
+
+
+def quant_matmul_rows(x, wq, ws, n, o, gs):
+    """quantize (quantization.rs:25-60) + matmul_q8 (functional.rs) for every row of x [T, n] -> [T, o]."""
+    T = x.shape[0]
+    G = n // gs
+    q = np.empty((T, n), np.int8); sc = np.empty((T, G), F)
+    for t in range(T):
+        q[t], sc[t] = quantize_q8(x[t], gs)
+    Wf = wq.reshape(o, G, gs).astype(np.float64); Xf = q.reshape(T, G, gs).astype(np.float64)
+    WS = ws.reshape(o, G)
+    out = np.zeros((T, o), F)
+    for g in range(G):
+        isum = (Xf[:, g] @ Wf[:, g].T)                             # exact: |sum| < 2^53
+        pgrp = (isum.astype(F) * WS[None, :, g]).astype(F)
+        pgrp = (pgrp * sc[:, g:g + 1]).astype(F)
+        out = (out + pgrp).astype(F)
+    return out
+
+
+def vision_forward(section, pixel_values):
+    """VisionTransformer::forward for ONE crop.  pixel_values [576, 588] (patch-major, as process() lays them out)."""
+    dim, hid, n_layers, n_heads, hs = struct.unpack_from("5I", section, 0)
+    eps = struct.unpack_from("f", section, 20)[0]
+    patch, image = struct.unpack_from("2I", section, 24)
+    gs = struct.unpack_from("I", section, 33)[0]
+    off = 128
+    def take(dt, *shape):
+        nonlocal off
+        a = np.frombuffer(section, dt, int(np.prod(shape)), off).reshape(shape); off += a.nbytes
+        return a
+    def take_q(o, n):
+        qs, ss = [], []
+        for _ in range(n_layers):
+            qs.append(take(np.int8, o, n)); ss.append(take(F, o * n // gs))
+        return qs, ss
+    kd = 3 * patch * patch
+    cls = take(F, dim); pe = take(F, dim, kd); pos = take(F, 577, dim)
+    ln1w, ln1b, ln2w, ln2b = take(F, n_layers, dim), take(F, n_layers, dim), take(F, n_layers, dim), take(F, n_layers, dim)
+    wq, wqb = take_q(dim, dim), take(F, n_layers, dim)
+    wk, wkb = take_q(dim, dim), take(F, n_layers, dim)
+    wv, wvb = take_q(dim, dim), take(F, n_layers, dim)
+    wo, wob = take_q(dim, dim), take(F, n_layers, dim)
+    w1, w1b = take_q(hid, dim), take(F, n_layers, hid)
+    w2, w2b = take_q(dim, hid), take(F, n_layers, dim)
+    prew, preb = take(F, dim), take(F, dim)
+    end = off
+
+    npch = (image // patch) ** 2
+    # conv as matmul_rest(out, x = kernel, w = pixels, n = 588, o = 576): out[d][p]; the tail reads x[r], i.e. kernel row 0
+    nb = kd // 8 * 8
+    body = lane_dot(pe[:, None, :nb], pixel_values[None, :, :nb])          # [dim, npch]
+    for r in range(nb, kd):
+        body = (body + (pixel_values[None, :, r] * pe[0, r]).astype(F)).astype(F)
+    emb = np.concatenate([cls[None, :], body.T.copy()], axis=0)            # [577, dim]
+    emb = (emb + pos).astype(F)
+    T = npch + 1
+    nrm = layernorm_rows(emb, prew, preb, eps)
+    scale = F(np.sqrt(F(hs)))
+    for l in range(n_layers - 1):
+        x = nrm.copy()
+        e = layernorm_rows(nrm, ln1w[l], ln1b[l], eps)
+        # the three projections share one quantisation of the row
+        q = ((quant_matmul_rows(e, wq[0][l], wq[1][l], dim, dim, gs) + wqb[l]).astype(F) / scale).astype(F)
+        k = (quant_matmul_rows(e, wk[0][l], wk[1][l], dim, dim, gs) + wkb[l]).astype(F)
+        v = (quant_matmul_rows(e, wv[0][l], wv[1][l], dim, dim, gs) + wvb[l]).astype(F)
+        ao = np.empty((T, dim), F)
+        for h in range(n_heads):
+            qh, kh, vh = q[:, h * hs:(h + 1) * hs], k[:, h * hs:(h + 1) * hs], v[:, h * hs:(h + 1) * hs]
+            att = lane_dot(qh[:, None, :], kh[None, :, :])                 # [Tq, Tk]
+            att = _expf_arr((att - att.max(axis=1, keepdims=True)).astype(F))
+            ssum = np.zeros(T, F)
+            for j in range(T):
+                ssum = (ssum + att[:, j]).astype(F)
+            att = (att / ssum[:, None]).astype(F)
+            nb2 = T // 8 * 8
+            o_ = lane_dot(att[:, None, :nb2], vh.T[None, :, :nb2])          # [Tq, hs]
+            for r in range(nb2, T):
+                o_ = (o_ + (vh[r][None, :] * att[:, r:r + 1]).astype(F)).astype(F)
+            ao[:, h * hs:(h + 1) * hs] = o_
+        e = (quant_matmul_rows(ao, wo[0][l], wo[1][l], dim, dim, gs) + wob[l]).astype(F)
+        e = (e + x).astype(F)
+        x = e.copy()
+        nrm = layernorm_rows(e, ln2w[l], ln2b[l], eps)
+        hdn = (quant_matmul_rows(nrm, w1[0][l], w1[1][l], dim, hid, gs) + w1b[l]).astype(F)
+        sg = (F(1.0) / (F(1.0) + _expf_arr(-(F(1.702) * hdn).astype(F))).astype(F)).astype(F)
+        hdn = (hdn * sg).astype(F)
+        e = (quant_matmul_rows(hdn, w2[0][l], w2[1][l], hid, dim, gs) + w2b[l]).astype(F)
+        nrm = (e + x).astype(F)
+    return end, nrm[1:]

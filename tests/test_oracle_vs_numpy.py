@@ -58,3 +58,20 @@ def test_image_projector_oracle_matches_numpy_transcription():
     assert ne == ref.shape[0]
     for r in rows:
         assert (got[r].view(np.uint32) == ref[r].view(np.uint32)).all(), f"embedding {r}: {np.flatnonzero(got[r] != ref[r])[:5]}"
+
+
+def test_vision_tower_oracle_matches_numpy_transcription():
+    """vision.rs:244-577 at the real ViT-L/14-336 geometry, one encoder layer, one crop: the C restatement against a
+    vectorised numpy statement written from the Rust source (patch conv with the matmul_rest tail, f32x8 lane sums,
+    sequential softmax sum, shared row quantisation for q/k/v, QuickGELU through libm expf)."""
+    from tools import synth_vision as V
+    cfg = V.VisionCfg(n_layers=2)
+    sec = V.build_vision_section(cfg, seed=21)
+    orc = O.VisionOracle(sec)
+    pv = V.pixel_values(cfg, 1, seed=8)
+    ref = orc.forward(pv, 1)[0]
+    end, got = NR.vision_forward(sec.tobytes(), pv[0])
+    assert end == orc.bytes_consumed == sec.size
+    assert got.shape == ref.shape
+    bad = np.flatnonzero(got.view(np.uint32).reshape(-1) != ref.view(np.uint32).reshape(-1))
+    assert bad.size == 0, f"{bad.size} of {ref.size} differ, first {bad[:5]}"

@@ -70,7 +70,7 @@ struct lmrs_ctx {
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
     // batched forward_layer (fill_kv_cache): device buffers for kPrefillTokens tokens, allocated on first use
-    float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr, *pf_t = nullptr; int8_t* pf_xq = nullptr;
+    float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr, *pf_t = nullptr; int8_t* pf_xq = nullptr; float* pf_att = nullptr; size_t pf_att_cap = 0;
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
@@ -684,7 +684,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->g_step) hipGraphExecDestroy(c->g_step);
     if (c->g_layers) hipGraphExecDestroy(c->g_layers);
-    for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t}) if (q) (void)hipFree(q);
+    for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) hipHostFree(c->h_logits);
     if (c->h_tok) hipHostFree(c->h_tok);
@@ -808,7 +808,19 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
         t.n_heads = (int)a.n_heads; t.n_kv_heads = (int)a.n_kv_heads; t.head_size = (int)a.head_size; t.seq_len = (int)a.seq_len; t.layer = (int)l;
         t.gemma = gemma; t.st = c->st;
-        HIP_OK(launch_attention_rows(t, p0, m, c->stream));
+        bool blocked = false;
+        if (attention_block_supported(t, m)) {
+            const size_t need = attention_block_scratch_floats(t.n_heads, m, p0 + m);
+            if (need <= ((size_t)1 << 28)) {                                   // <= 1 GiB of score slabs; longer contexts: per-token kernel
+                if (need > c->pf_att_cap) {
+                    if (c->pf_att) { HIP_OK(hipStreamSynchronize(c->stream)); (void)hipFree(c->pf_att); c->pf_att = nullptr; c->pf_att_cap = 0; }
+                    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_att), need * 4)); c->pf_att_cap = need;
+                }
+                HIP_OK(launch_attention_block(t, p0, m, c->pf_att, c->stream));
+                blocked = true;
+            }
+        }
+        if (!blocked) HIP_OK(launch_attention_rows(t, p0, m, c->stream));
         // quantize | Wo | x += ... (Gemma: -> pf_t)                                     (:550-576)
         HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, att, m, c->pf_xq, c->pf_xs, c->stream));
         g.wq = L.wo; g.ws = L.so; g.n = att; g.o = dim; g.out = gemma ? c->pf_t : c->pf_x;

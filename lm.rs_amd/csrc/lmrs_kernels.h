@@ -109,6 +109,10 @@ hipError_t launch_rows_prologue(float* x, const float* rms_w, const float* delta
 hipError_t launch_rows_addnorm(float* x, const float* delta, const float* w, float eps, int n, int n_tok, hipStream_t s);
 hipError_t launch_rope_rows(float* q, const float* k_raw, float* k_cache, const float* rope, int n_heads, int n_kv_heads, int hs, int seq_len,
                             int layer, int pos0, int n_tok, hipStream_t s);
+// block attention for batched prefill (Llama / Phi): 64 queries of one head per workgroup; scratch: attention_block_scratch_floats(..)
+bool attention_block_supported(const AttnArgs& a, int n_tok);
+size_t attention_block_scratch_floats(int n_heads, int n_tok, int T);
+hipError_t launch_attention_block(const AttnArgs& a, int pos0, int n_tok, float* scratch, hipStream_t s);
 hipError_t launch_attention_rows(const AttnArgs& a, int pos0, int n_tok, hipStream_t s);
 
 // ---- CLIP vision tower (lmrs_vision.inc; reference src/vision.rs:244-577), dim 1024 / 16 heads x 64 / 577 tokens per crop

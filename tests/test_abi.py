@@ -73,3 +73,26 @@ def test_product_package_never_touches_the_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f in ("lmrs_device_math.h",), f"{f} mentions the oracle"
                 assert "lmrs_ref_" not in txt, f
+
+
+def test_cpp_host_mirror_compiles_and_links_against_the_abi(tmp_path):
+    """lm.rs_amd/hostcpp: the C++ mirrors of Transformer / VisionTransformer / PHI3VProcessor build with plain g++ against
+    include/lmrs_hip.h and link with the shared library (no GPU needed to link)."""
+    import subprocess
+    import lmrs_amd
+    lmrs_amd.build()
+    src = tmp_path / "use.cpp"
+    src.write_text('#include "lm.rs_amd/hostcpp/vision.hpp"\n'
+                   'int main(int argc, char**) {\n'
+                   '    if (argc > 99) {\n'
+                   '        auto [m, used] = lmrs_host::Transformer::create(nullptr, 0);\n'
+                   '        auto [v, vused] = lmrs_host::VisionTransformer::create(nullptr, 0);\n'
+                   '        auto p = lmrs_host::PHI3VProcessor::create(nullptr, 0);\n'
+                   '        auto [f, ns] = v.forward({}, 1); (void)p.forward(f, ns, 12, 1, 1); (void)m.forward_argmax(0, 0); (void)used; (void)vused;\n'
+                   '    }\n'
+                   '    return 0;\n}\n')
+    lib_dir = os.path.dirname(lmrs_amd.LIB_PATH)
+    exe = tmp_path / "use"
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", ROOT, str(src), "-L", lib_dir, "-llmrs_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)],
+                   check=True, capture_output=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", os.path.join(ROOT, "lm.rs_amd", "hostcpp", "chat_greedy.cpp")], check=True, capture_output=True)

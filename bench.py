@@ -91,7 +91,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # LMRS_BENCH_FORCE_DIST=1: take the N > 1 code path (torch.distributed + RCCL communicator + sharded context) with a world of
+    # one - the only way to exercise that path, torch's bundled HIP / RCCL runtimes included, on a single-GPU box
+    force_dist = os.environ.get("LMRS_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -125,7 +131,8 @@ def main():
 
     # N > 1: ONE decode stream, weight matrices row-split over the N GPUs (one process per GPU), RCCL all-gathers
     # of the per-shard slices over xGMI between the fused kernels.  Token ids stay identical.
-    if world > 1:
+    sharded = dist is not None
+    if sharded:
         uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
         model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
     else:
@@ -152,7 +159,7 @@ def main():
         path = {"bytes_per_step": round(path_bytes / K), "us_per_step": round(elapsed / K * 1e6, 2),
                 "achieved": round(path_bytes / elapsed / 1e9, 1), "frac": round(path_bytes / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
                 "kernel_launches_per_step": n_launch, "device_event_us_per_step": round(dev_sec / K * 1e6, 2)}
-        if world > 1:
+        if sharded:
             roofline = {"bound": "hbm", "kernel": "whole step (per-kernel timing hook is single-GPU only)", "achieved": path["achieved"],
                         "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": path["frac"], "traffic": None, "path": path,
                         "sharded_step_is_one_hipgraph": model.shard_uses_graph()}
@@ -188,7 +195,7 @@ def main():
             parity = {"tokens_compared": int(n_new), "tokens_equal": bool((ref == gen[:n_new]).all())}
         # ---- batched forward_layer (fill_kv_cache): the path's only dense contraction, int8 MFMA
         prefill = None
-        if world == 1 and args.qtype == "q8_0" and cfg.model_type != S.GEMMA:
+        if not sharded and args.qtype == "q8_0" and cfg.model_type != S.GEMMA:
             n_pf = 256
             emb = model.get_embeddings(S.prompt_tokens(cfg, n_pf, 4321))
             best = 1e9

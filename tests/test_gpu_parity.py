@@ -243,6 +243,25 @@ def test_fill_kv_cache_batched_prefill(L, cfg, q, n_tok, pos0):
         t = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
+@pytest.mark.parametrize("cfg,n_tok,pos0", [("mini-llama", 150, 9), ("mini-llama3b", 70, 0)])
+def test_batched_attention_with_memory_resident_scores(L, monkeypatch, cfg, n_tok, pos0):
+    """Beyond 2048 keys the block softmax keeps its scores in the slab instead of LDS; LMRS_ATT_LDS_KEYS forces that variant at a
+    length the CPU path finishes quickly.  Same bit-equality as the LDS variant."""
+    monkeypatch.setenv("LMRS_ATT_LDS_KEYS", "32")
+    img = S.build_image(cfg, S.Q8_0, seed=23)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    if pos0:
+        warm = S.prompt_tokens(cfg, pos0, 5)
+        a0 = m.get_embeddings(warm); b0 = orc.get_embeddings(warm)
+        assert m.fill_kv_cache(a0, 0) == orc.fill_kv_cache(b0, 0) == pos0
+    toks = S.prompt_tokens(cfg, n_tok, 23)
+    a = m.get_embeddings(toks); b = orc.get_embeddings(toks)
+    assert m.fill_kv_cache(a, pos0) == orc.fill_kv_cache(b, pos0) == pos0 + n_tok
+    assert_bit_equal(a, b, "residual stream after the batched layers (scores in memory)")
+    lo = orc.forward(3, pos0 + n_tok)
+    assert_bit_equal(m.forward(3, pos0 + n_tok), lo, "decode on the prefilled cache")
+
+
 @pytest.mark.parametrize("cfg,n_prompt", [("mini-llama", 200), ("mini-phi", 90)])
 def test_generate_greedy_with_a_long_prompt(L, cfg, n_prompt):
     """generate_greedy feeds all prompt tokens but the last through the batched forward_layer (only their K/V rows matter,

@@ -495,7 +495,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     if (a.group_size != 128) return fail("group_size != 128 is not supported by the HIP kernels (the reference exporter always quantises with 128)");
     const size_t dim = a.dim, att = (size_t)a.n_heads * a.head_size, kv = (size_t)a.n_kv_heads * a.head_size, hid = a.hidden_dim, V = a.vocab_size;
     if (dim % 128 || att % 128 || hid % 128) return fail("dim, n_heads*head_size and hidden_dim must be multiples of 128");
-    if (dim > 10240 || att > 10240 || hid > 10240) return fail("vector length above 10240 not supported");
+    if (dim > 10240 || att > 10240 || hid > 16384) return fail("vector lengths above 10240 (dim, attention) / 16384 (hidden) are not supported");
     if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128 && a.head_size != 256) return fail("head_size must be 64, 96, 128 or 256 (the model families lm.rs supports)");
     int ndev = 0;
     hipError_t de = hipGetDeviceCount(&ndev);

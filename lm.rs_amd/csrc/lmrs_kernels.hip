@@ -44,7 +44,7 @@ constexpr int kGS = 128;             // quantisation group size (the reference e
 
 // Thread t owns elements e = i*1024 + 4t .. +3 for i = 0..P-1  (P = ceil(n / 1024)), so that 32
 // consecutive lanes own one 128-element quantisation group.
-constexpr int kMaxP = 10;            // n <= 10240 (NP, the per-lane float4 count, is a template parameter <= kMaxP)
+constexpr int kMaxP = 16;            // n <= 16384 (NP, the per-lane float4 count, is a template parameter <= kMaxP)
 
 // RMSNorm (functional.rs:48-78) of x[n] (held in v[]), result written back into v[].
 // wv[] = the norm weights of the same elements (loaded by the caller, early, so that no late global
@@ -652,7 +652,7 @@ struct GemvShape { int L, U, NP; };
 
 static GemvShape pick_shape(const GemvArgs& a, int epi) {
     const int cl = a.q4 ? 4 : 8, G = a.n / kGS;
-    const int NP = a.n <= 2048 ? 2 : (a.n <= 4096 ? 4 : 10);
+    const int NP = a.n <= 2048 ? 2 : (a.n <= 4096 ? 4 : (a.n <= 10240 ? 10 : 16));
     const int maxL = (epi == EPI_SWIGLU || epi == EPI_GELU) ? 32 : 64;
     int best = cl;
     for (int L = cl; L <= maxL; L *= 2) {
@@ -676,6 +676,9 @@ static GemvShape pick_shape(const GemvArgs& a, int epi) {
     X(8, 16, 10, PRO_PREQ, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_RESID, false) \
     X(8, 16, 10, PRO_RMS_QUANT, EPI_STORE, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_QKV, false)              \
     X(8, 16, 10, PRO_RMS_QUANT, EPI_SWIGLU, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_GELU, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_CLS, false) \
+    /* generic, 10240 < n <= 16384 (hidden_dim 14336 of Gemma-2-9B / Llama-3.1-8B): the inputs that are only quantised */      \
+    X(8, 16, 16, PRO_PREQ, EPI_STORE, false) X(8, 16, 16, PRO_QUANT, EPI_STORE, false) X(8, 16, 16, PRO_QUANT, EPI_RESID, false) \
+    X(4, 16, 16, PRO_PREQ, EPI_STORE, true) X(4, 16, 16, PRO_QUANT, EPI_STORE, true) X(4, 16, 16, PRO_QUANT, EPI_RESID, true) \
     /* n = 2048 (Llama-3.2-1B dim; Gemma-2-2B att_dim) */                                                  \
     X(32, 4, 2, PRO_RMS_QUANT, EPI_QKV, false) X(32, 4, 2, PRO_QUANT, EPI_RESID, false) X(32, 4, 2, PRO_QUANT, EPI_STORE, false) \
     X(8, 16, 2, PRO_RMS_QUANT, EPI_SWIGLU, false) X(8, 16, 2, PRO_RMS_QUANT, EPI_CLS, false) X(8, 16, 2, PRO_RMS_QUANT, EPI_QKV, false) \
@@ -705,8 +708,9 @@ static bool gemv_instantiated(int L, int U, int NP, int pro, int epi, bool q4) {
 static GemvShape resolve_shape(const GemvArgs& a, int pro, int epi) {
     GemvShape sh = pick_shape(a, epi);
     if (!gemv_instantiated(sh.L, sh.U, sh.NP, pro, epi, a.q4 != 0)) {
-        if (gemv_instantiated(sh.L, sh.U, 10, pro, epi, a.q4 != 0)) sh.NP = 10;
-        else sh = {a.q4 ? 4 : 8, 16, 10};
+        const int big = a.n <= 10240 ? 10 : 16;
+        if (gemv_instantiated(sh.L, sh.U, big, pro, epi, a.q4 != 0)) sh.NP = big;
+        else sh = {a.q4 ? 4 : 8, 16, big};
     }
     return sh;
 }

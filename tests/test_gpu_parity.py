@@ -175,7 +175,7 @@ def test_golden_fixture_forward(L, golden_dir, name):
     assert (m2.generate_greedy(prompt, len(toks_gold)) == toks_gold).all()
 
 
-@pytest.mark.parametrize("cfg", ["mini-llama", "mini-llama3b", "mini-phi"])
+@pytest.mark.parametrize("cfg", ["mini-llama", "mini-llama3b", "mini-phi", "mini-llama8b"])
 def test_mini_models_logits_bit_exact(L, cfg):
     img = S.build_image(cfg, S.Q8_0, seed=11)
     m = L.Transformer(img); orc = O.Oracle(img)
@@ -193,9 +193,10 @@ def test_mini_models_logits_bit_exact(L, cfg):
         assert kv == orc.args.n_kv_heads * orc.args.head_size
 
 
-@pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q4_0), ("mini-gemma", S.Q4_0), ("mini-gemma", S.Q8_0)])
+@pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q4_0), ("mini-gemma", S.Q4_0), ("mini-gemma", S.Q8_0), ("mini-gemma9b", S.Q8_0), ("tiny-wide-att", S.Q4_0)])
 def test_mini_q4_and_gemma_logits_bit_exact(L, cfg, q):
-    """Q4_0 weights/activations and the Gemma variant (GELU, four norms, soft-caps, head 256): BASELINE configs[2] shapes."""
+    """Q4_0 weights/activations and the Gemma variant (GELU, four norms, soft-caps, head 256): BASELINE configs[2] shapes.
+    mini-gemma9b / tiny-wide-att: n_heads * head_size > dim (Gemma-2-9B, transformer.rs:497-499) on the generic kernels."""
     img = S.build_image(cfg, q, seed=12)
     m = L.Transformer(img); orc = O.Oracle(img)
     prompt = S.prompt_tokens(cfg, 4, 12)

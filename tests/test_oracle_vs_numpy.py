@@ -75,3 +75,17 @@ def test_vision_tower_oracle_matches_numpy_transcription():
     assert got.shape == ref.shape
     bad = np.flatnonzero(got.view(np.uint32).reshape(-1) != ref.view(np.uint32).reshape(-1))
     assert bad.size == 0, f"{bad.size} of {ref.size} differ, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("q", [S.Q8_0, S.Q4_0])
+def test_oracle_matches_numpy_when_attention_is_wider_than_the_model(q):
+    """n_heads * head_size > dim (Gemma-2-9B's geometry; the reference grows its activation buffer, transformer.rs:497-499)."""
+    img = S.build_image("tiny-wide-att", q, seed=3)
+    orc = O.Oracle(img); ref = NR.NumpyModel(img)
+    prompt = S.prompt_tokens("tiny-wide-att", 3, 3)
+    tok = None
+    for pos in range(6):
+        t = int(prompt[pos]) if pos < 3 else tok
+        lo = orc.forward(t, pos).copy(); ln = ref.forward(t, pos)
+        assert (lo.view(np.uint32) == ln.view(np.uint32)).all(), f"pos {pos}"
+        tok = int(np.argmax(lo))

@@ -66,6 +66,10 @@ CONFIGS = {
     "mini-llama3b": ModelCfg("mini-llama3b", 3072, 8192, 2, 24, 128, 8, 4096, 256, 1e-5, 500000.0, LLAMA),
     "mini-gemma": ModelCfg("mini-gemma", 2304, 9216, 2, 8, 256, 4, 4096, 256, 1e-6, 10000.0, GEMMA),
     "mini-phi": ModelCfg("mini-phi", 3072, 8192, 2, 32, 96, 32, 4096, 256, 1e-5, 10000.0, PHI),
+    # Gemma-2-9B geometry: n_heads * head_size (4096) > dim (3584), the case of transformer.rs:497-499
+    "mini-gemma9b": ModelCfg("mini-gemma9b", 3584, 14336, 2, 16, 256, 8, 4096, 256, 1e-6, 10000.0, GEMMA),
+    "mini-llama8b": ModelCfg("mini-llama8b", 4096, 14336, 2, 32, 128, 8, 4096, 256, 1e-5, 500000.0, LLAMA),
+    "tiny-wide-att": ModelCfg("tiny-wide-att", 256, 512, 2, 4, 128, 2, 512, 64, 1e-6, 10000.0, GEMMA),
 }
 
 

@@ -28,6 +28,9 @@
 //     L2-resident f32 vector: it runs while the workgroup's first weight loads are in flight and
 //     saves a dependent kernel boundary (~1.2-1.9 us on this chip) per use.
 #include <hip/hip_ext.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include "lmrs_device_math.h"
 #include "lmrs_kernels.h"
@@ -636,6 +639,16 @@ void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop) { t_ev_start = st
     } while (0)
 #define LMRS_LAUNCH(kern, grid, smem, s, a) LMRS_LAUNCH_NT(kern, grid, kBlock, smem, s, a)
 
+// Kernels that ask for more than 64 KB of dynamic LDS need the attribute once per (function, device).
+static void allow_big_lds(const void* fn) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.insert({fn, dev}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 static size_t gemv_smem(const GemvArgs& a, int pro) {
     const int n = a.n, G = n / kGS;
     size_t s = ((n + 15) & ~15) + (size_t)((G + 3) & ~3) * 4;
@@ -1074,11 +1087,7 @@ int attention_chunk(int head_size) {
 
 template <int HS, bool GEMMA>
 static hipError_t launch_attention_hsg(const AttnArgs& a, size_t smem, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<HS, GEMMA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    allow_big_lds(reinterpret_cast<const void*>(attention_kernel<HS, GEMMA>));
     hipLaunchKernelGGL((attention_kernel<HS, GEMMA>), dim3(a.n_heads), dim3(kBlock), smem, s, a);
     return hipGetLastError();
 }

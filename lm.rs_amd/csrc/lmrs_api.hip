@@ -69,6 +69,8 @@ struct lmrs_ctx {
     // pinned host
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
+    // long contexts: step graphs whose attention is the split pair, one per context bucket (256-key chunks: 4, 8, 16, 32)
+    hipGraphExec_t g_step_long[4] = {nullptr, nullptr, nullptr, nullptr}; float* att_S = nullptr; int att_split_chunks = 0; int att_split_pos = 0;
     // batched forward_layer (fill_kv_cache): device buffers for kPrefillTokens tokens, allocated on first use
     float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr, *pf_t = nullptr; int8_t* pf_xq = nullptr; float* pf_att = nullptr; size_t pf_att_cap = 0;
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
@@ -169,7 +171,8 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.seq_len = a.seq_len; t.layer = l;
     t.gemma = gemma; t.st = c->st;
     t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-    HIP_OK(launch_attention(t, c->stream));
+    if (c->att_split_chunks) HIP_OK(launch_attention_split(t, c->att_S, c->att_split_chunks, c->stream));
+    else HIP_OK(launch_attention(t, c->stream));
     // 3. quantize | Wo | x += ...                                       (:550-576)
     g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -667,6 +670,8 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     if (!sharded) {
         CK(capture(c, true, &c->g_step));
         CK(capture(c, false, &c->g_layers));
+        // from this position on a step uses the split attention (scores by key chunk, V by dim slice): graphs captured on first use
+        if (!c->dbg && !c->fused_cls) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
     } else if (!group_mode) {
         // RCCL collectives inside a captured graph: use it when the runtime accepts it, else enqueue every step
         if (capture(c, true, &c->g_step)) { c->g_step = nullptr; c->eager = true; (void)hipGetLastError(); g_err.clear(); }
@@ -683,6 +688,8 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->g_step) hipGraphExecDestroy(c->g_step);
+    for (auto& g : c->g_step_long) if (g) hipGraphExecDestroy(g);
+    if (c->att_S) (void)hipFree(c->att_S);
     if (c->g_layers) hipGraphExecDestroy(c->g_layers);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
@@ -700,7 +707,21 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
 extern "C" const lmrs_args* lmrs_get_args(const lmrs_ctx* c) { return c ? &c->args : nullptr; }
 
 // one decode step on the context's stream: the captured graph, or (sharded, capture refused) eager launches
-static int launch_step(lmrs_ctx* c) {
+static int launch_step(lmrs_ctx* c, uint32_t pos) {
+    if (c->g_step && c->att_split_pos > 0 && (int)pos >= c->att_split_pos) {
+        // bucket b covers positions below 1024 << b
+        int b = 0;
+        while (b < 3 && pos >= (1024u << b)) ++b;
+        if (!c->g_step_long[b]) {
+            if (!c->att_S) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->att_S), attention_split_scratch_floats((int)c->args.n_heads, (int)c->args.seq_len) * 4));
+            c->att_split_chunks = 4 << b;
+            const int rc = capture(c, true, &c->g_step_long[b]);
+            c->att_split_chunks = 0;
+            if (rc) return -1;
+        }
+        HIP_OK(hipGraphLaunch(c->g_step_long[b], c->stream));
+        return 0;
+    }
     if (c->g_step) { HIP_OK(hipGraphLaunch(c->g_step, c->stream)); return 0; }
     if (c->comm && c->eager) return enqueue_step_sharded(c);
     return fail("this context is a member of a shard group: drive it with lmrs_group_forward");
@@ -715,7 +736,7 @@ static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
     HIP_OK(hipMemcpyAsync(c->tokens + pos, c->h_tok, 4, hipMemcpyHostToDevice, c->stream));
     if (set_state(c, pos, 0)) return -1;
     HIP_OK(launch_embed(embed_args(c), c->stream));
-    return launch_step(c);
+    return launch_step(c, pos);
 }
 
 extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** logits) {
@@ -904,7 +925,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     }
     if (set_state(c, start_pos + (uint32_t)done, start_pos + (uint32_t)n_prompt)) return -1;
     HIP_OK(launch_embed(embed_args(c), c->stream));
-    for (size_t s = done; s < steps; ++s) if (launch_step(c)) return -1;
+    for (size_t s = done; s < steps; ++s) if (launch_step(c, start_pos + (uint32_t)s)) return -1;
     HIP_OK(hipEventRecord(c->ev1, c->stream));
     if (n_new) HIP_OK(hipMemcpyAsync(c->h_tok, c->tokens + start_pos + n_prompt, (size_t)n_new * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));

@@ -79,6 +79,9 @@ void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop);   // measurement
 int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
 bool gemv_is_static(const GemvArgs& a, int pro, int epi); // a compile-time-shape kernel exists for this launch
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// long contexts: scores by (head, 256-key chunk), softmax + V by (head, quarter of the dims); S: attention_split_scratch_floats(..)
+size_t attention_split_scratch_floats(int n_heads, int seq_len);
+hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks, hipStream_t s);
 hipError_t launch_embed(const EmbedArgs& a, hipStream_t s);
 hipError_t launch_addvec(float* x, const float* d, int n, hipStream_t st);
 hipError_t launch_addnorm(float* x, const float* delta, const float* w, int n, float eps, hipStream_t st);   // Gemma: x += rmsnorm(delta, 1 + w)

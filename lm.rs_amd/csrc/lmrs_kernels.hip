@@ -1111,6 +1111,139 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Attention of one new token at LONG contexts, as two launches.  One workgroup per head streams the whole K and V of its
+// kv head through one CU (≈24 GB/s per CU): 89 us per layer at 4000 positions, of which only the softmax sum and the V
+// accumulation - one chain of T adds each - are inherently serial.  Here the scores are cut by (head, 256-key chunk), all
+// independent, into S[head][t]; then one workgroup per (head, quarter of the head dims) redoes the cheap softmax of its head
+// (max / exp / the sum chain / divide - the four copies run concurrently) and runs the V chains of its HS/4 dims, streaming
+// a quarter of the V bytes.  Same operations in the same order per value as attention_body: bit-identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAttSplitDims = 4;
+template <int HS, bool GEMMA>
+__global__ __launch_bounds__(kBlock) void attention_split_scores_kernel(const AttnArgs a, float* S) {
+    __shared__ __attribute__((aligned(16))) float q[HS];
+    __shared__ __attribute__((aligned(16))) float kn[HS];
+    constexpr int half = HS / 2;
+    const int h = blockIdx.x, tid = threadIdx.x;
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
+    const int pos = a.st->pos, T = pos + 1;
+    const int t0 = blockIdx.y * kBlock;
+    if (t0 >= T) return;
+    const int SQ = a.seq_len;
+    float* kT = att_k_head(a, kvh, HS);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(kT, 0, HS * SQ * 4, 0x00020000);
+    constexpr int KG = HS / 4 <= 32 ? HS / 4 : 16;
+    const int t = t0 + tid, tc = t < T ? t : T - 1;
+    f32x4v kk[KG];
+    att_kload<KG>(kk, krs, tc * 16, 0, SQ);
+    const bool mine = pos >= t0 && pos < t0 + kBlock;       // this chunk holds the new key: rotate it, store it (every head of the kv head: same values)
+    for (int j = tid; j < half; j += kBlock) {              // RoPE (transformer.rs:480-491), as in attention_body
+        const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
+        const float fcr = cs.x, fci = cs.y;
+        {
+            const float v0 = a.q[h * HS + j], v1 = a.q[h * HS + j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            q[j] = a0 - a1; q[j + half] = b0 + b1;
+        }
+        if (mine) {
+            const float v0 = a.k_raw[kvh * HS + j], v1 = a.k_raw[kvh * HS + j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            const float r0 = a0 - a1, r1 = b0 + b1;
+            kn[j] = r0; kn[j + half] = r1;
+            kT[(((size_t)(j >> 2) * SQ + pos) << 2) + (j & 3)] = r0;
+            kT[(((size_t)((j + half) >> 2) * SQ + pos) << 2) + ((j + half) & 3)] = r1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (tc == pos) {                                        // batch 0 was loaded before the new key existed: patch it from LDS
+#pragma unroll
+        for (int u = 0; u < KG; ++u) { const float4 t4 = reinterpret_cast<const float4*>(kn)[u]; kk[u] = f32x4v{t4.x, t4.y, t4.z, t4.w}; }
+    }
+    int wpos = pos;
+    if constexpr (GEMMA) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
+    const float sqrt_hs = sqrtf((float)HS);
+    float score = att_score_chain<HS, KG>(kk, krs, tc * 16, q, SQ);
+    score = score / sqrt_hs;
+    if constexpr (GEMMA) {                                  // transformer.rs:518-526
+        score = score / 50.0f;
+        score = (float)tanh((double)score);
+        score = score * 50.0f;
+        score = score + (((unsigned)(wpos - t) <= 4096u) ? 0.0f : -2.3819763e38f);
+    }
+    if (t < T) S[(size_t)h * SQ + t] = score;
+}
+
+template <int HS, bool GEMMA>
+__global__ __launch_bounds__(kBlock) void attention_split_values_kernel(const AttnArgs a, const float* S) {
+    constexpr int HP = HS / kAttSplitDims, RS = HP + 4;
+    static_assert(HP % 4 == 0, "dim slice");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int h = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul, kv_dim = a.n_kv_heads * HS;
+    const int pos = a.st->pos, T = pos + 1, CH = a.chunk;
+    const uint64_t etab = exp2f_tab_lane();
+    float* red = reinterpret_cast<float*>(smem);            // 16 floats of reduction scratch
+    float* tile = red + 16;                                 // CH (+32) rows of RS floats
+    float* att = tile + (size_t)(CH + 32) * RS;             // T (+32 floats of zero padding, +32 of read-ahead)
+    const float* vbase = a.v_cache + (size_t)a.layer * a.seq_len * kv_dim + kvh * HS + sl * HP;
+    const int nchunks = (T + CH - 1) / CH;
+    float4 vreg[kAttF4];
+    att_gload<HP, kAttF4>(vreg, vbase, 0, T, CH, kv_dim);   // the first V chunk is in flight across the softmax
+    // softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide - as in attention_body
+    float lmax = __uint_as_float(0xff800000u);
+    for (int t = tid; t < T; t += kBlock) { const float sc = S[(size_t)h * a.seq_len + t]; att[t] = sc; lmax = fmaxf(lmax, sc); }
+    lmax = wave64_max(lmax);
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    lds_barrier();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    for (int t0 = 0; t0 < T; t0 += kBlock) {                // whole waves call expf together (it shuffles)
+        const int t = t0 + tid;
+        const float e = expf_glibc_t(t < T ? att[t] - mx : 0.0f, etab);
+        if (t < T) att[t] = e;
+    }
+    if (tid < 32) att[T + tid] = 0.0f;
+    lds_barrier();
+    if (tid == 0) red[4] = serial_sum16<1>(0.0f, att, T);
+    lds_barrier();
+    const float sum = red[4];
+    for (int t = tid; t < T; t += kBlock) att[t] = att[t] / sum;
+    lds_barrier();
+    // weighted sum of values (transformer.rs:533-541) for this workgroup's HP dims
+    float o = 0.0f;
+    for (int c = 0; c < nchunks; ++c) {
+        const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
+        att_tstore<HP, kAttF4, true>(vreg, tile, att + t0, t0, T, CH, -1, nullptr);
+        lds_barrier();
+        if (c + 1 < nchunks) att_gload<HP, kAttF4>(vreg, vbase, t0 + CH, T, CH, kv_dim);
+        if (tid < HP) o = serial_sum16<RS, false>(o, tile + tid, ct);
+        lds_barrier();
+    }
+    if (tid < HP) a.out[h * HS + sl * HP + tid] = o;
+}
+
+size_t attention_split_scratch_floats(int n_heads, int seq_len) { return (size_t)n_heads * seq_len; }
+
+template <int HS, bool GEMMA>
+static hipError_t launch_attention_split_hsg(const AttnArgs& a0, float* S, int n_key_chunks, hipStream_t s) {
+    AttnArgs a = a0;
+    constexpr int HP = HS / kAttSplitDims;
+    a.chunk = 256;
+    if (a.chunk * (HP / 4) > kAttF4 * kBlock) return hipErrorInvalidValue;
+    const size_t smem = (size_t)(16 + (size_t)(a.chunk + 32) * (HP + 4) + ((a.seq_len + 3) & ~3) + 64) * 4;
+    allow_big_lds(reinterpret_cast<const void*>(attention_split_values_kernel<HS, GEMMA>));
+    hipLaunchKernelGGL((attention_split_scores_kernel<HS, GEMMA>), dim3(a.n_heads, n_key_chunks), dim3(kBlock), 0, s, a, S);
+    hipLaunchKernelGGL((attention_split_values_kernel<HS, GEMMA>), dim3(a.n_heads, kAttSplitDims), dim3(kBlock), smem, s, a, (const float*)S);
+    return hipGetLastError();
+}
+// n_key_chunks: 256-key chunks covering the longest context this launch (graph) will see
+hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks, hipStream_t s) {
+#define AS(HS_) return a.gemma ? launch_attention_split_hsg<HS_, true>(a, S, n_key_chunks, s) : launch_attention_split_hsg<HS_, false>(a, S, n_key_chunks, s);
+    switch (a.head_size) { case 64: AS(64) case 96: AS(96) case 128: AS(128) case 256: AS(256) default: return hipErrorInvalidValue; }
+#undef AS
+}
+
+// ------------------------------------------------------------------------------------------------
 // Embedding row (transformer.rs:324-332; quantization.rs:25-42) — dequantised on the fly, which is
 // bit-identical to reading the reference's load-time f32 copy of the table.
 // ------------------------------------------------------------------------------------------------

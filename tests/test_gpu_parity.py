@@ -341,6 +341,24 @@ def test_long_context_multi_chunk_attention(L, cfg, n_steps):
     assert_bit_equal(m.forward(int(ref[-1]), pos), orc.forward(int(ref[-1]), pos), f"{cfg} logits at pos {pos}")
 
 
+@pytest.mark.parametrize("cfg,q,n_steps,split_pos", [("mini-llama-long", S.Q8_0, 1100, 40), ("mini-phi-long", S.Q8_0, 300, 20), ("mini-llama3b", S.Q8_0, 200, 16),
+                                                     ("mini-gemma", S.Q4_0, 200, 16)])
+def test_split_attention_for_long_contexts(L, monkeypatch, cfg, q, n_steps, split_pos):
+    """From LMRS_ATT_SPLIT_POS on (default 384) a decode step computes its scores by (head, 256-key chunk) and the softmax + V
+    chains by (head, quarter of the head dims) - two launches instead of one workgroup per head.  Forced early here: the switch
+    between the two step graphs, both context buckets of the split graph (below / above 1024 positions), every head size and
+    the Gemma score path.  Token ids over the whole run + bit-equal logits at the end."""
+    monkeypatch.setenv("LMRS_ATT_SPLIT_POS", str(split_pos))
+    img = S.build_image(cfg, q, seed=52)
+    prompt = S.prompt_tokens(cfg, 8, 52)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    got = m.generate_greedy(prompt, n_steps)
+    ref = orc.generate_greedy(prompt, n_steps)
+    assert (got == ref).all(), f"first mismatch at {int(np.flatnonzero(got != ref)[0])}"
+    pos = 8 + n_steps - 1
+    assert_bit_equal(m.forward(int(ref[-1]), pos), orc.forward(int(ref[-1]), pos), f"{cfg} logits at pos {pos}")
+
+
 # ------------------------------------------------------------------ row sharding (SURVEY.md §8e)
 @pytest.mark.parametrize("cfg,world", [("mini-llama", 2), ("mini-llama", 8), ("mini-llama3b", 4), ("mini-phi", 8)])
 def test_row_sharding_is_bit_identical(L, cfg, world):

@@ -65,7 +65,8 @@ int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, i
 int lmrs_comm_unique_id(void* out128);
 
 /* Host-only: the row ranges shard `rank` of `world` owns.  plan[0..9] = q-head first,count; kv-head first,count;
- * wo/w2 row first,count; gate/up pair first,count; classifier row first,count. */
+ * wo/w2 row first,count; gate/up pair first,count; classifier row first,count.  wo and w2 are replicated by default
+ * (every shard: first 0, count dim - no gather after them); LMRS_SHARD_SPLIT_OUT=1 row-splits them as well. */
 int lmrs_shard_plan(const lmrs_args* args, int rank, int world, int* plan10);
 /* 1: the sharded step is one captured hipGraph (RCCL inside); 0: enqueued call by call; -1: not an RCCL shard. */
 int lmrs_shard_uses_graph(const lmrs_ctx* ctx);

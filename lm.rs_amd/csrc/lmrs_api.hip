@@ -83,6 +83,7 @@ struct lmrs_ctx {
     int att_full = 0;                              // n_heads * head_size of the whole model
     int dim_l = 0, hid_l = 0, voc_l = 0;           // rows of wo/w2, gate-up pairs of w13, classifier rows owned here
     int d0 = 0, h0 = 0, v0 = 0, a0 = 0;            // first owned row / pair / vocab row / att column
+    bool rep_out = true;                           // wo / w2 replicated (all dim rows on every shard): no gather after them
     ncclComm_t comm = nullptr;                     // RCCL communicator (one process per GPU); null in group mode
     bool eager = false;                            // sharded step could not be captured: enqueue it every call
     float* part = nullptr;                         // [world][values(cls_grid) | indices(cls_grid)] argmax partials
@@ -247,14 +248,15 @@ int enqueue_step(lmrs_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // Row-sharded step (world > 1), cut into segments at the points where every shard needs the others' rows.
 //   segment 4l+0: [x += tmp] qkv(own heads) -> attention(own heads)      then gather att_out   (att/W per shard)
-//   segment 4l+1: wo (own rows)                                          then gather tmp       (dim/W)
+//   segment 4l+1: wo (all rows, replicated; or own rows)                 [then gather tmp      (dim/W) if row-split]
 //   segment 4l+2: x += tmp ; w1/w3 (own pairs) -> silu*up                 then gather h         (hidden/W)
-//   segment 4l+3: w2 (own rows)                                          then gather tmp       (dim/W)
+//   segment 4l+3: w2 (all rows, replicated; or own rows)                 [then gather tmp      (dim/W) if row-split]
 //   segment 4L  : x += tmp ; classifier (own vocab rows) + argmax partials  then gather partials
 //   segment 4L+1: argmax over all shards' partials, next-token embedding (replicated)
 // Gathers are in place: shard r's slice sits at buf + r * count on every shard.
 // ------------------------------------------------------------------------------------------------
 struct GatherDesc { float* buf; size_t count; };
+static bool shard_split_out() { static const bool v = getenv("LMRS_SHARD_SPLIT_OUT") != nullptr; return v; }
 
 int n_segments(const lmrs_ctx* c) { return 4 * (int)c->args.n_layers + 2; }
 
@@ -263,9 +265,9 @@ GatherDesc gather_after(lmrs_ctx* c, int seg) {
     if (seg < L4) {
         switch (seg & 3) {
             case 0: return {c->att_out, (size_t)c->att_dim};
-            case 1: return {c->tmp, (size_t)c->dim_l};
+            case 1: return c->rep_out ? GatherDesc{nullptr, 0} : GatherDesc{c->tmp, (size_t)c->dim_l};
             case 2: return {c->h, (size_t)c->hid_l};
-            default: return {c->tmp, (size_t)c->dim_l};
+            default: return c->rep_out ? GatherDesc{nullptr, 0} : GatherDesc{c->tmp, (size_t)c->dim_l};
         }
     }
     if (seg == L4) return {c->part, (size_t)2 * c->cls_grid};
@@ -411,8 +413,9 @@ extern "C" int lmrs_shard_plan(const lmrs_args* a, int rank, int world, int* pla
     if (!a || !plan || world < 1 || rank < 0 || rank >= world) return fail("bad argument");
     if (a->n_kv_heads % world || a->dim % world || a->hidden_dim % world || a->vocab_size % world)
         return fail("world must divide n_kv_heads, dim, hidden_dim and vocab_size");
-    const int nh = a->n_heads / world, nkv = a->n_kv_heads / world, dl = a->dim / world, hl = a->hidden_dim / world, vl = a->vocab_size / world;
-    const int p[10] = {rank * nh, nh, rank * nkv, nkv, rank * dl, dl, rank * hl, hl, rank * vl, vl};
+    const bool rep = !shard_split_out();                      // wo / w2 rows: replicated on every shard by default
+    const int nh = a->n_heads / world, nkv = a->n_kv_heads / world, dl = rep ? (int)a->dim : (int)a->dim / world, hl = a->hidden_dim / world, vl = a->vocab_size / world;
+    const int p[10] = {rank * nh, nh, rank * nkv, nkv, rep ? 0 : rank * dl, dl, rank * hl, hl, rank * vl, vl};
     memcpy(plan, p, sizeof p);
     return 0;
 }
@@ -511,8 +514,13 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     if (world > 1 && (a.n_kv_heads % W || dim % W || hid % W || V % W))
         return fail("world must divide n_kv_heads, dim, hidden_dim and vocab_size");
     const size_t hs = a.head_size;
-    const size_t att_l = att / W, kv_l = kv / W, dim_l = dim / W, hid_l = hid / W, voc_l = V / W;
-    const size_t a0 = rank * att_l, k0 = rank * kv_l, d0 = rank * dim_l, h0 = rank * hid_l, v0 = rank * voc_l;
+    // wo and w2 (the projections back to the residual stream) are REPLICATED by default: every shard computes all dim rows
+    // from the gathered att_out / h, so the residual needs no gather of its own - two all-gathers per layer instead of four,
+    // for 4 + 17 MB of extra weight reads per layer and shard (1-3 us) against two ~10-20 us latency-bound collectives.
+    // LMRS_SHARD_SPLIT_OUT=1 restores the fully row-split form.
+    const bool rep_out = !shard_split_out();
+    const size_t att_l = att / W, kv_l = kv / W, dim_l = rep_out ? dim : dim / W, hid_l = hid / W, voc_l = V / W;
+    const size_t a0 = rank * att_l, k0 = rank * kv_l, d0 = rep_out ? 0 : rank * dim_l, h0 = rank * hid_l, v0 = rank * voc_l;
     (void)hs;
 
     lmrs_ctx* c = new lmrs_ctx();
@@ -520,6 +528,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     c->rank = rank; c->world = world; c->att_full = (int)att;
     c->att_dim = (int)att_l; c->kv_dim = (int)kv_l; c->dim_l = (int)dim_l; c->hid_l = (int)hid_l; c->voc_l = (int)voc_l;
     c->a0 = (int)a0; c->d0 = (int)d0; c->h0 = (int)h0; c->v0 = (int)v0;
+    c->rep_out = rep_out;
     const bool sharded = world > 1 || uid != nullptr;
     auto cleanup = [&]() { lmrs_destroy(c); return -1; };
 #define CK(call) do { if ((call)) return cleanup(); } while (0)

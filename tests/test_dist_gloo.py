@@ -39,10 +39,10 @@ def _worker(rank, world, port, q):
         a.dim, a.hidden_dim, a.n_heads, a.n_kv_heads, a.head_size, a.vocab_size = cfg.dim, cfg.hidden_dim, cfg.n_heads, cfg.n_kv_heads, cfg.head_size, cfg.vocab_size
         plan = lmrs_amd.shard_plan(a, rank, world)
         rng = np.random.default_rng(5)                        # same stream on every rank
-        n = o = cfg.dim
+        n = cfg.dim; o = cfg.hidden_dim                      # a gate projection: rows split like the (gate, up) pairs
         wq = rng.integers(-127, 128, size=o * n, dtype=np.int8); ws = rng.uniform(1e-4, 3e-3, size=o * n // 128).astype(np.float32)
         xq, xs = O.quantize((rng.standard_normal(n) * 2).astype(np.float32))
-        r0, cnt = plan["dim_rows"]
+        r0, cnt = plan["hidden_pairs"]
         mine = O.matmul_q8(xq, xs, wq[r0 * n:(r0 + cnt) * n], ws[r0 * n // 128:(r0 + cnt) * n // 128], n, cnt)
         parts = [torch.zeros(cnt) for _ in range(world)]
         dist.all_gather(parts, torch.from_numpy(mine))
@@ -50,7 +50,8 @@ def _worker(rank, world, port, q):
         ref = O.matmul_q8(xq, xs, wq, ws, n, o)
         assert (full.view(np.uint32) == ref.view(np.uint32)).all()
         # every row / head / pair / vocab row owned exactly once across ranks
-        for key, total in (("q_heads", cfg.n_heads), ("kv_heads", cfg.n_kv_heads), ("dim_rows", cfg.dim), ("hidden_pairs", cfg.hidden_dim), ("vocab_rows", cfg.vocab_size)):
+        assert plan["dim_rows"] == (0, cfg.dim)              # wo / w2: replicated, every shard computes the whole residual update
+        for key, total in (("q_heads", cfg.n_heads), ("kv_heads", cfg.n_kv_heads), ("hidden_pairs", cfg.hidden_dim), ("vocab_rows", cfg.vocab_size)):
             mine_rng = torch.tensor(plan[key]); allr = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
             dist.all_gather(allr, mine_rng)
             cover = sorted((int(t[0]), int(t[1])) for t in allr)

@@ -284,7 +284,7 @@ int run_segment(lmrs_ctx* c, int seg) {
         const int l = seg >> 2; const DevLayer& L = c->layers[l];
         switch (seg & 3) {
             case 0: {
-                if (l > 0) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+                if (l > 0 && !c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
                 g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
                 g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
                 g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
@@ -298,23 +298,23 @@ int run_segment(lmrs_ctx* c, int seg) {
                 break;
             }
             case 1:
-                g.wq = L.wo; g.ws = L.so; g.n = c->att_full; g.o = c->dim_l; g.xin = c->att_out; g.out = c->tmp + c->d0;
-                HIP_OK(launch_gemv(g, PRO_QUANT, EPI_STORE, c->stream));
+                g.wq = L.wo; g.ws = L.so; g.n = c->att_full; g.o = c->dim_l; g.xin = c->att_out; g.out = c->rep_out ? c->x : c->tmp + c->d0;
+                HIP_OK(launch_gemv(g, PRO_QUANT, c->rep_out ? EPI_RESID : EPI_STORE, c->stream));   // replicated: x += wo(att) in the epilogue, as on one GPU
                 break;
             case 2:
-                HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+                if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
                 g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * c->hid_l; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h + c->h0;
                 HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_SWIGLU, c->stream));
                 break;
             default:
-                g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = c->dim_l; g.xin = c->h; g.out = c->tmp + c->d0;
-                HIP_OK(launch_gemv(g, PRO_QUANT, EPI_STORE, c->stream));
+                g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = c->dim_l; g.xin = c->h; g.out = c->rep_out ? c->x : c->tmp + c->d0;
+                HIP_OK(launch_gemv(g, PRO_QUANT, c->rep_out ? EPI_RESID : EPI_STORE, c->stream));
                 break;
         }
         return 0;
     }
     if (seg == L4) {
-        HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+        if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
         GemvArgs k = cls_args(c);
         HIP_OK(launch_gemv(k, PRO_RMS_QUANT, EPI_CLS, c->stream));
         return 0;

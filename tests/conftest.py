@@ -9,6 +9,27 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _cpu_budget() -> int:
+    """CPUs this process may actually use: affinity mask, capped by the cgroup quota (OpenMP only sees the former)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# The CPU oracle is OpenMP code with many short parallel regions.  On a box whose container is limited to a few CPUs while all
+# of the host's are visible, 16 spinning threads on 2 cores turn a 40-second suite into many minutes: size the team to the real
+# budget and let idle threads sleep when the budget is small.  (bench.py's cpu_baseline does not go through here.)
+_n = _cpu_budget()
+os.environ.setdefault("LMRS_REF_THREADS", str(min(16, _n)))
+if _n < 16:
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

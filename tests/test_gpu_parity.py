@@ -316,18 +316,18 @@ def test_llama_1b_q8_greedy_token_ids(L):
 
 
 def test_llama_1b_q8_long_prompt_at_full_size(L):
-    """Llama-3.2-1B Q8_0 at full size with a 1100-token prompt: three chunks of the batched prefill (int8 matrix-core GEMMs,
-    block attention), then 40 decode steps on the split-attention graph of the 1024..2047 bucket - token ids identical to the
-    token-by-token CPU path, logits of one more step bit-equal."""
+    """Llama-3.2-1B Q8_0 at full size with a 600-token prompt: two chunks of the batched prefill (int8 matrix-core GEMMs,
+    block attention), then 40 decode steps on the split-attention graph - token ids identical to the token-by-token CPU path,
+    logits of one more step bit-equal.  (Checked once at 1100 tokens as well: three chunks, the 1024..2047 bucket.)"""
     cfg = "llama-3.2-1b"
     img = S.build_image(cfg, S.Q8_0, seed=1234)
-    prompt = S.prompt_tokens(cfg, 1100, 99)
+    prompt = S.prompt_tokens(cfg, 600, 99)
     m = L.Transformer(img)
     got = m.generate_greedy(prompt, 40)
     orc = O.Oracle(img)
     ref = orc.generate_greedy(prompt, 40)
     assert (got == ref).all(), f"first mismatch at {int(np.flatnonzero(got != ref)[0])}"
-    pos = 1100 + 39
+    pos = 600 + 39
     assert_bit_equal(m.forward(int(ref[-1]), pos), orc.forward(int(ref[-1]), pos), f"1B logits at pos {pos}")
 
 

@@ -186,6 +186,17 @@ def main():
             import oracle_lib as O
             if args.cpu_threads > 0:
                 os.environ["LMRS_REF_THREADS"] = str(args.cpu_threads)
+            elif "LMRS_REF_THREADS" not in os.environ:
+                # the team the host can really run: affinity mask capped by the container's CPU quota (OpenMP sees only the former,
+                # and 16 spinning threads on a 2-CPU quota are an order of magnitude slower than 2)
+                budget = len(os.sched_getaffinity(0))
+                try:
+                    quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                    if quota != "max":
+                        budget = min(budget, max(1, int(quota) // int(period)))
+                except (OSError, ValueError):
+                    pass
+                os.environ["LMRS_REF_THREADS"] = str(min(16, budget))
             orc = O.Oracle(img)
             n_new = min(cpu_steps, K) + 1
             ref, sec = orc.generate_greedy(prompt, n_new, timing=True)

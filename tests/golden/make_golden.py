@@ -13,6 +13,8 @@
    CPU ORACLE (oracle/liblmrs_oracle.so) on those files.  The forward arithmetic of the reference
    cannot be executed here (Rust, no toolchain) so these are regression vectors for the oracle and
    the HIP path, NOT reference outputs: forward parity remains "unpinned" (see DESIGN.md).
+3. `tiny_phi_vision_q8.json` — sizes and SHA-256 of a multimodal file (text + CLIP tower + projector sections) written by the
+   reference exporter with --vision-config: pins the vision / processor section layout tools/synth_vision.py restates.
 """
 import json
 import os
@@ -55,7 +57,67 @@ def export_with_reference(cfg, q_type, seed, out_base):
         subprocess.run(cmd, check=True, cwd=REF, stdout=subprocess.DEVNULL)
 
 
+MM_NAME, MM_TEXT_CFG, MM_SEED = "tiny_phi_vision_q8", "tiny-phi", 9
+MM_VSEED, MM_PSEED = 31, 32
+
+
+def mm_vision_cfg():
+    from tools import synth_vision as V
+    return V.VisionCfg(dim=128, hidden_dim=512, n_layers=2, n_heads=2, head_size=64)
+
+
+def mm_expected_image():
+    """What tools/synth_lmrs.py + tools/synth_vision.py write for the multimodal fixture: text image with the multimodal flag set,
+    then the vision section, then the processor section."""
+    from tools import synth_vision as V
+    cfg = S.CONFIGS[MM_TEXT_CFG]
+    text = S.build_image(cfg, S.Q8_0, MM_SEED).copy()
+    text[54] = 1                                                      # header: multimodal flag (export.py:80)
+    vcfg = mm_vision_cfg()
+    vis = V.build_vision_section(vcfg, MM_VSEED)
+    proc = V.build_processor_section(4 * vcfg.dim, cfg.dim, MM_PSEED)
+    return text, vis, proc
+
+
+def export_multimodal():
+    """The reference exporter on a tiny Phi + CLIP + projector checkpoint (--vision-config): pins the layout of the vision and
+    processor sections (export.py:126-170) that tools/synth_vision.py restates.  Only sizes and the SHA-256 are committed."""
+    import hashlib
+    import torch
+    from safetensors.torch import save_file
+    from tools import synth_vision as V
+    cfg = S.CONFIGS[MM_TEXT_CFG]
+    vcfg = mm_vision_cfg()
+    assert vcfg.hidden_dim == 4 * vcfg.dim
+    base = os.path.join(HERE, MM_NAME)
+    with tempfile.TemporaryDirectory() as td:
+        sd = dict(S.hf_state_dict(cfg, MM_SEED))
+        sd.update(V.hf_vision_state_dict(vcfg, 4 * vcfg.dim, cfg.dim, MM_VSEED, MM_PSEED))
+        save_file({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, os.path.join(td, "model.safetensors"))
+        with open(os.path.join(td, "config.json"), "w") as f:
+            json.dump(S.hf_config(cfg), f)
+        with open(os.path.join(td, "vision.json"), "w") as f:
+            json.dump(V.hf_vision_config(vcfg), f)
+        out = os.path.join(td, "mm")
+        subprocess.run([sys.executable, os.path.join(REF, "export.py"), "--files", os.path.join(td, "model.safetensors"), "--config",
+                        os.path.join(td, "config.json"), "--vision-config", os.path.join(td, "vision.json"), "--save-path", out,
+                        "--type", "PHI", "--quantize", "--quantize-type", "1"], check=True, cwd=REF, stdout=subprocess.DEVNULL)
+        ref = np.fromfile(out + ".lmrs", np.uint8)
+    text, vis, proc = mm_expected_image()
+    mine = np.concatenate([text, vis, proc])
+    same = ref.size == mine.size and bool((ref == mine).all())
+    print(f"{MM_NAME}: export.py wrote {ref.size} bytes (text {text.size} + vision {vis.size} + processor {proc.size}); synth writers identical: {same}")
+    if not same:
+        n = min(ref.size, mine.size); d = np.flatnonzero(ref[:n] != mine[:n])
+        print("   first difference at byte", int(d[0]) if d.size else n)
+    assert same
+    with open(base + ".json", "w") as f:
+        json.dump({"bytes": int(ref.size), "text_bytes": int(text.size), "vision_bytes": int(vis.size), "processor_bytes": int(proc.size),
+                   "sha256": hashlib.sha256(ref.tobytes()).hexdigest()}, f, indent=1)
+
+
 def main():
+    export_multimodal()
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
     for name, cfg_name, q_type, seed in FIXTURES:

@@ -63,3 +63,26 @@ def test_malformed_images_are_rejected():
         O.Oracle(img[:-4])
     with pytest.raises(RuntimeError):
         O.Oracle(img[:100])
+
+
+def test_multimodal_sections_match_the_reference_exporter(golden_dir):
+    """The vision and processor sections tools/synth_vision.py writes (the inputs of every image-path test) are, byte for byte,
+    what the reference's export.py --vision-config wrote for the same tensors (tests/golden/make_golden.py recorded its size and
+    SHA-256), and the CPU restatements of Transformer::new / VisionTransformer::new / PHI3VProcessor::new walk the file the way
+    chat.rs:84-91 does: each consumes exactly its section."""
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden as G
+    fx = json.load(open(os.path.join(golden_dir, "tiny_phi_vision_q8.json")))
+    text, vis, proc = G.mm_expected_image()
+    img = np.concatenate([text, vis, proc])
+    assert (text.size, vis.size, proc.size, img.size) == (fx["text_bytes"], fx["vision_bytes"], fx["processor_bytes"], fx["bytes"])
+    assert hashlib.sha256(img.tobytes()).hexdigest() == fx["sha256"]
+    t = O.Oracle(img)
+    assert t.bytes_consumed == fx["text_bytes"] and t.args.multimodal
+    v = O.VisionOracle(img[t.bytes_consumed:])
+    assert v.bytes_consumed == fx["vision_bytes"]
+    p = O.ProcessorOracle(img[t.bytes_consumed + v.bytes_consumed:])
+    assert p.bytes_consumed == fx["processor_bytes"]

@@ -34,36 +34,53 @@ def vision_header(cfg: VisionCfg, q_type: int = Q8_0, gs: int = 128) -> bytes:
     return h + b"\0" * (128 - len(h))
 
 
-def build_vision_section(cfg: VisionCfg = VisionCfg(), seed: int = 99, gs: int = 128) -> np.ndarray:
-    """-> uint8 array: 128-byte header + tensors in the order VisionTransformer::new reads them (Q8_0)."""
+VIS_PREFIX = "model.vision_embed_tokens.img_processor.vision_model."
+
+
+def vision_tensors(cfg: VisionCfg = VisionCfg(), seed: int = 99):
+    """The float tensors of the tower in the order export.py writes them (:126-151): a list of
+    (Hugging Face key suffix with `{l}` for per-layer tensors, [array per layer] or [array], quantised?)."""
     L, dim, hid = cfg.n_layers, cfg.dim, cfg.hidden_dim
-    kdim = 3 * cfg.patch_size * cfg.patch_size
     rng = np.random.default_rng(seed)
-    parts = [np.frombuffer(vision_header(cfg, Q8_0, gs), np.uint8)]
 
     def f32(shape, sigma, base=0.0):
         return (base + sigma * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
 
-    def put_f32(a):
-        parts.append(np.ascontiguousarray(a, np.float32).reshape(-1).view(np.uint8))
+    def per_layer_rows(a):                          # one [L, n] draw -> L vectors
+        return [a[l] for l in range(L)]
 
-    def put_quant(per_layer_shape, sigma):
-        for _ in range(L):
-            q, s = quantize_q80(f32(per_layer_shape, sigma), gs)
-            parts.append(q.view(np.uint8).reshape(-1)); parts.append(np.ascontiguousarray(s, np.float32).reshape(-1).view(np.uint8))
+    t = []
+    t.append(("embeddings.class_embedding", [f32((dim,), 0.05)], False))
+    t.append(("embeddings.patch_embedding.weight", [f32((dim, 3 * cfg.patch_size * cfg.patch_size), 0.03).reshape(dim, 3, cfg.patch_size, cfg.patch_size)], False))
+    t.append(("embeddings.position_embedding.weight", [f32((N_POS, dim), 0.05)], False))
+    t.append(("encoder.layers.{l}.layer_norm1.weight", per_layer_rows(f32((L, dim), 0.1, 1.0)), False))
+    t.append(("encoder.layers.{l}.layer_norm1.bias", per_layer_rows(f32((L, dim), 0.05)), False))
+    t.append(("encoder.layers.{l}.layer_norm2.weight", per_layer_rows(f32((L, dim), 0.1, 1.0)), False))
+    t.append(("encoder.layers.{l}.layer_norm2.bias", per_layer_rows(f32((L, dim), 0.05)), False))
+    for name, shape, sigma, nb in (("self_attn.q_proj", (dim, dim), 0.03, dim), ("self_attn.k_proj", (dim, dim), 0.03, dim), ("self_attn.v_proj", (dim, dim), 0.03, dim),
+                                   ("self_attn.out_proj", (dim, dim), 0.03, dim), ("mlp.fc1", (hid, dim), 0.03, hid), ("mlp.fc2", (dim, hid), 0.02, dim)):
+        t.append((f"encoder.layers.{{l}}.{name}.weight", [f32(shape, sigma) for _ in range(L)], True))
+        t.append((f"encoder.layers.{{l}}.{name}.bias", per_layer_rows(f32((L, nb), 0.05)), False))
+    t.append(("pre_layrnorm.weight", [f32((dim,), 0.1, 1.0)], False))
+    t.append(("pre_layrnorm.bias", [f32((dim,), 0.05)], False))
+    return t
 
-    put_f32(f32((dim,), 0.05))                       # class_embedding
-    put_f32(f32((dim, kdim), 0.03))                  # patch_embedding.weight [dim][3*14*14]
-    put_f32(f32((N_POS, dim), 0.05))                 # position_embedding.weight
-    put_f32(f32((L, dim), 0.1, 1.0)); put_f32(f32((L, dim), 0.05))      # layer_norm1 w, b
-    put_f32(f32((L, dim), 0.1, 1.0)); put_f32(f32((L, dim), 0.05))      # layer_norm2 w, b
-    for _ in range(3):                               # q, k, v
-        put_quant((dim, dim), 0.03); put_f32(f32((L, dim), 0.05))
-    put_quant((dim, dim), 0.03); put_f32(f32((L, dim), 0.05))           # out_proj
-    put_quant((hid, dim), 0.03); put_f32(f32((L, hid), 0.05))           # fc1
-    put_quant((dim, hid), 0.02); put_f32(f32((L, dim), 0.05))           # fc2
-    put_f32(f32((dim,), 0.1, 1.0)); put_f32(f32((dim,), 0.05))          # pre_layrnorm w, b
+
+def _section(header: bytes, tensors, gs: int) -> np.ndarray:
+    parts = [np.frombuffer(header, np.uint8)]
+    for _, arrays, quant in tensors:
+        for a in arrays:
+            if quant:
+                q, sc = quantize_q80(np.ascontiguousarray(a, np.float32).reshape(a.shape[0], -1), gs)
+                parts.append(q.view(np.uint8).reshape(-1)); parts.append(np.ascontiguousarray(sc, np.float32).reshape(-1).view(np.uint8))
+            else:
+                parts.append(np.ascontiguousarray(a, np.float32).reshape(-1).view(np.uint8))
     return np.concatenate(parts)
+
+
+def build_vision_section(cfg: VisionCfg = VisionCfg(), seed: int = 99, gs: int = 128) -> np.ndarray:
+    """-> uint8 array: 128-byte header + tensors in the order VisionTransformer::new reads them (Q8_0)."""
+    return _section(vision_header(cfg, Q8_0, gs), vision_tensors(cfg, seed), gs)
 
 
 def pixel_values(cfg: VisionCfg, num_crops: int, seed: int = 7) -> np.ndarray:
@@ -73,21 +90,45 @@ def pixel_values(cfg: VisionCfg, num_crops: int, seed: int = 7) -> np.ndarray:
     return np.random.default_rng(seed).standard_normal((num_crops, n, 3 * cfg.patch_size ** 2), dtype=np.float32)
 
 
-def build_processor_section(hidden_dim: int = 4096, text_dim: int = 3072, seed: int = 123, gs: int = 128) -> np.ndarray:
-    """Processor section (export.py:155-170, read back by src/processor.rs:168-232): 13-byte header padded to 128, glb_GN,
-    sub_GN, the two projector matrices (Q8_0), their biases."""
+def processor_tensors(hidden_dim: int = 4096, text_dim: int = 3072, seed: int = 123):
+    """glb_GN, sub_GN, the projector MLP, in the order export.py writes them (:166-169); keys relative to model.vision_embed_tokens."""
     rng = np.random.default_rng(seed)
-    h = struct.pack("II", hidden_dim, text_dim) + struct.pack("B", Q8_0) + struct.pack("I", gs)
-    assert len(h) == 13
-    parts = [np.frombuffer(h + b"\0" * (128 - len(h)), np.uint8)]
 
     def f32(shape, sigma):
         return (sigma * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
 
-    parts.append(f32((hidden_dim,), 0.5).view(np.uint8))                        # glb_GN
-    parts.append(f32((hidden_dim,), 0.5).view(np.uint8))                        # sub_GN
-    for shape, sigma in (((text_dim, hidden_dim), 0.02), ((text_dim, text_dim), 0.02)):
-        q, s = quantize_q80(f32(shape, sigma), gs)
-        parts.append(q.view(np.uint8).reshape(-1)); parts.append(np.ascontiguousarray(s, np.float32).reshape(-1).view(np.uint8))
-    parts.append(f32((text_dim,), 0.05).view(np.uint8)); parts.append(f32((text_dim,), 0.05).view(np.uint8))
-    return np.concatenate(parts)
+    glb, sub = f32((hidden_dim,), 0.5), f32((hidden_dim,), 0.5)
+    w0, w1 = f32((text_dim, hidden_dim), 0.02), f32((text_dim, text_dim), 0.02)
+    b0, b1 = f32((text_dim,), 0.05), f32((text_dim,), 0.05)
+    return [("glb_GN", [glb.reshape(1, 1, -1)], False), ("sub_GN", [sub.reshape(1, 1, 1, -1)], False),
+            ("img_projection.0.weight", [w0], True), ("img_projection.2.weight", [w1], True),
+            ("img_projection.0.bias", [b0], False), ("img_projection.2.bias", [b1], False)]
+
+
+def processor_header(hidden_dim: int, text_dim: int, q_type: int = Q8_0, gs: int = 128) -> bytes:
+    h = struct.pack("II", hidden_dim, text_dim) + struct.pack("B", q_type) + struct.pack("I", gs)
+    assert len(h) == 13
+    return h + b"\0" * (128 - len(h))
+
+
+def build_processor_section(hidden_dim: int = 4096, text_dim: int = 3072, seed: int = 123, gs: int = 128) -> np.ndarray:
+    """Processor section (export.py:155-170, read back by src/processor.rs:168-232): 13-byte header padded to 128, glb_GN,
+    sub_GN, the two projector matrices (Q8_0), their biases."""
+    return _section(processor_header(hidden_dim, text_dim, Q8_0, gs), processor_tensors(hidden_dim, text_dim, seed), gs)
+
+
+def hf_vision_state_dict(cfg: VisionCfg, hidden_dim: int, text_dim: int, vseed: int, pseed: int) -> dict:
+    """The same float tensors under the Hugging Face names export.py looks for (Phi-3.5-vision checkpoint layout)."""
+    sd = {}
+    for key, arrays, _ in vision_tensors(cfg, vseed):
+        for l, a in enumerate(arrays):
+            sd[VIS_PREFIX + key.format(l=l)] = a
+    for key, arrays, _ in processor_tensors(hidden_dim, text_dim, pseed):
+        sd["model.vision_embed_tokens." + key] = arrays[0]
+    return sd
+
+
+def hf_vision_config(cfg: VisionCfg) -> dict:
+    return {"vision_config": {"hidden_size": cfg.dim, "intermediate_size": cfg.hidden_dim, "num_hidden_layers": cfg.n_layers,
+                              "num_attention_heads": cfg.n_heads, "layer_norm_eps": cfg.layernorm_eps, "patch_size": cfg.patch_size,
+                              "image_size": cfg.image_size}}

@@ -175,7 +175,10 @@ class NumpyModel:
         val = F(F(pos) * freq)
         return F(F(_libm.cosf(float(val))) * sf), F(F(_libm.sinf(float(val))) * sf)
 
-    def layer(self, x, l, pos):
+    def layer(self, x, l, pos, wpos=None):
+        """forward_layer for one token at `pos`; wpos: the `pos` argument of the forward_layer CALL, which the Gemma window test uses
+        for every token of a batch (transformer.rs:525, u32 arithmetic) - None: a single-token call."""
+        wpos = pos if wpos is None else wpos
         gem = self.model_type == 0
         dim, hs, att, kv = self.dim, self.hs, self.att, self.kv
         xn = rmsnorm(x, self.rms_att[l], self.eps, gem)
@@ -206,7 +209,7 @@ class NumpyModel:
                 s_ = F(s_ / F(_libm.sqrtf(float(hs))))
                 if gem:
                     s_ = F(s_ / F(50.0)); s_ = F(_libm.tanh(float(s_))); s_ = F(s_ * F(50.0))
-                    s_ = F(s_ + (F(0.0) if pos - t <= 4096 else F(-2.3819763e38)))
+                    s_ = F(s_ + (F(0.0) if ((wpos - t) & 0xFFFFFFFF) <= 4096 else F(-2.3819763e38)))
                 sc[t] = s_
             mx = sc.max()
             sm = F(0.0)
@@ -242,6 +245,17 @@ class NumpyModel:
         if gem:
             return (x + rmsnorm(ff, self.rms_post_ffn[l], self.eps, True)).astype(F)
         return (x + ff).astype(F)
+
+    def fill_kv_cache(self, embeddings, curr_pos):
+        """Transformer::fill_kv_cache (transformer.rs:672-684): forward_layer over all n tokens for each layer in turn (token i sits
+        at curr_pos + i and attends to keys 0 .. curr_pos + i, :507,:533); mutates `embeddings` [n, dim] in place, returns
+        curr_pos + n.  Per token the arithmetic is that of a single-token call (quantisation groups never straddle tokens),
+        except Gemma's window test, which uses the call's `pos`."""
+        n = embeddings.shape[0]
+        for l in range(self.L):
+            for i in range(n):
+                embeddings[i] = self.layer(embeddings[i].copy(), l, curr_pos + i, wpos=curr_pos)
+        return curr_pos + n
 
     def forward(self, token, pos):
         x = self.embed(token)

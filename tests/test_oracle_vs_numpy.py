@@ -89,3 +89,26 @@ def test_oracle_matches_numpy_when_attention_is_wider_than_the_model(q):
         lo = orc.forward(t, pos).copy(); ln = ref.forward(t, pos)
         assert (lo.view(np.uint32) == ln.view(np.uint32)).all(), f"pos {pos}"
         tok = int(np.argmax(lo))
+
+
+@pytest.mark.parametrize("name,cfg,seed,n_tok,pos0", [("tiny_llama_q8", "tiny-llama", 7, 6, 0), ("tiny_phi_q8", "tiny-phi", 9, 5, 2),
+                                                      ("tiny_gemma_q8", "tiny-gemma", 8, 5, 3), ("tiny_llama_q4", "tiny-llama", 7, 4, 1)])
+def test_fill_kv_cache_oracle_matches_numpy_transcription(golden_dir, name, cfg, seed, n_tok, pos0):
+    """Transformer::fill_kv_cache (transformer.rs:672-684, forward_layer with sl > 1): the mutated embeddings and the logits of
+    the decode step that follows, C restatement against the numpy transcription.  pos0 > 0: positions before the batch are
+    filled token by token first (Gemma: the batched call then masks with its first position, :525).  Q4_0: the decode-form
+    product per token on both sides."""
+    img = np.fromfile(os.path.join(golden_dir, name + ".lmrs"), np.uint8)
+    orc = O.Oracle(img); ref = NR.NumpyModel(img)
+    warm = S.prompt_tokens(cfg, pos0, seed + 1)
+    for pos in range(pos0):
+        orc.forward(int(warm[pos]), pos); ref.forward(int(warm[pos]), pos)
+    toks = S.prompt_tokens(cfg, n_tok, seed)
+    a = orc.get_embeddings(toks).reshape(n_tok, -1).copy()
+    b = np.stack([ref.embed(int(t)) for t in toks])
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()            # get_embeddings: dequantised rows, no Gemma scaling (transformer.rs:659-669)
+    flat = a.reshape(-1)
+    assert orc.fill_kv_cache(flat, pos0) == ref.fill_kv_cache(b, pos0) == pos0 + n_tok
+    assert (flat.view(np.uint32) == b.reshape(-1).view(np.uint32)).all(), np.flatnonzero(flat != b.reshape(-1))[:5]
+    lo = orc.forward(3, pos0 + n_tok).copy(); ln = ref.forward(3, pos0 + n_tok)
+    assert (lo.view(np.uint32) == ln.view(np.uint32)).all()

@@ -356,10 +356,10 @@ int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out) {
         if (!rc) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
     }
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return -1; }
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return -1; }
     if (e != hipSuccess) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
     e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
     return 0;
 }
@@ -694,22 +694,22 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
 
 extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->g_step) hipGraphExecDestroy(c->g_step);
-    for (auto& g : c->g_step_long) if (g) hipGraphExecDestroy(g);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->g_step) (void)hipGraphExecDestroy(c->g_step);
+    for (auto& g : c->g_step_long) if (g) (void)hipGraphExecDestroy(g);
     if (c->att_S) (void)hipFree(c->att_S);
-    if (c->g_layers) hipGraphExecDestroy(c->g_layers);
+    if (c->g_layers) (void)hipGraphExecDestroy(c->g_layers);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
-    if (c->h_logits) hipHostFree(c->h_logits);
-    if (c->h_tok) hipHostFree(c->h_tok);
-    if (c->h_st) hipHostFree(c->h_st);
-    if (c->h_err) hipHostFree(c->h_err);
-    if (c->arena) hipFree(c->arena);
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->h_logits) (void)hipHostFree(c->h_logits);
+    if (c->h_tok) (void)hipHostFree(c->h_tok);
+    if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -1038,7 +1038,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
 namespace {
 struct Scratch {          // RAII device buffers for the op entry points
     std::vector<void*> p;
-    ~Scratch() { for (void* q : p) hipFree(q); }
+    ~Scratch() { for (void* q : p) (void)hipFree(q); }
     void* get(size_t bytes) { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 4) != hipSuccess) return nullptr; p.push_back(q); return q; }
 };
 int op_begin(int device) {

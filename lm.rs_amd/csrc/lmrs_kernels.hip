@@ -926,7 +926,7 @@ __device__ __forceinline__ float att_score_chain(f32x4v (&kk)[NG], __amdgpu_buff
 template <int HS, int NF, bool COH, bool PRE = false, bool GEMMA = false, bool ROT = false>
 __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, uint64_t etab, const AttPre& pre = AttPre()) {
     static_assert(!PRE || HS / 2 <= kBlock, "one RoPE pair per lane");
-    constexpr int half = HS / 2, HS4 = HS / 4, RS = HS + 4;
+    constexpr int half = HS / 2, RS = HS + 4;
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const int kv_dim = a.n_kv_heads * HS;
     const int T = pos + 1;

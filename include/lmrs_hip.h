@@ -54,27 +54,28 @@ enum { LMRS_GEMMA = 0, LMRS_LLAMA = 1, LMRS_PHI = 2 };
  * The host image is not referenced after return. */
 int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx** out, size_t* bytes_consumed);
 
-/* Row-sharded variant: this process is shard `rank` of `world`
+/* Row-sharded variant (no reference counterpart - the reference is one process on one host; replaces the same
+ * Transformer::new, transformer.rs:134): this process is shard `rank` of `world`
  * (one process per GPU).  `nccl_unique_id` points at the 128-byte ncclUniqueId created
  * by rank 0 and distributed by the host (e.g. torch.distributed broadcast); it may be
  * NULL when world == 1.  Results are bit-identical to world == 1. */
 int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world,
                         const void* nccl_unique_id, lmrs_ctx** out, size_t* bytes_consumed);
 
-/* Writes the 128-byte ncclUniqueId for lmrs_create_sharded (call on rank 0). */
+/* Writes the 128-byte ncclUniqueId for lmrs_create_sharded (call on rank 0).  No reference counterpart. */
 int lmrs_comm_unique_id(void* out128);
 
 /* Host-only: the row ranges shard `rank` of `world` owns.  plan[0..9] = q-head first,count; kv-head first,count;
  * wo/w2 row first,count; gate/up pair first,count; classifier row first,count.  wo and w2 are replicated by default
  * (every shard: first 0, count dim - no gather after them); LMRS_SHARD_SPLIT_OUT=1 row-splits them as well. */
 int lmrs_shard_plan(const lmrs_args* args, int rank, int world, int* plan10);
-/* 1: the sharded step is one captured hipGraph (RCCL inside); 0: enqueued call by call; -1: not an RCCL shard. */
+/* 1: the sharded step is one captured hipGraph (RCCL inside); 0: enqueued call by call; -1: not an RCCL shard.  No reference counterpart. */
 int lmrs_shard_uses_graph(const lmrs_ctx* ctx);
 
 /* Verification aid (no reference counterpart): `world` row shards of one model as `world` contexts on ONE device,
  * exchanged by device-to-device copies instead of RCCL, so the sharding can be checked bit for bit on a 1-GPU box. */
 int lmrs_group_create(const uint8_t* file, size_t len, int device, int world, lmrs_ctx** shards, size_t* bytes_consumed);
-/* One decode step over such a group.  *logits (optional) = the assembled logits (pinned, owned by shards[0]);
+/* One decode step over such a group (Transformer::forward, transformer.rs:316-384, on the sharded layout).  *logits (optional) = the assembled logits (pinned, owned by shards[0]);
  * *next (optional) = the greedy token. */
 int lmrs_group_forward(lmrs_ctx** shards, int world, uint32_t token, uint32_t pos, float** logits, uint32_t* next);
 
@@ -132,7 +133,7 @@ int lmrs_op_quantize_q4(int device, uint8_t* q, float* s, const float* x, size_t
 int lmrs_op_rmsnorm(int device, float* o, const float* x, const float* weight, size_t size, float eps, int add_unit_offset);
 /* functional.rs:122-140 (in place) */
 int lmrs_op_softmax(int device, float* x, size_t n);
-/* f32::exp as used by softmax / SiLU: the device's bit-exact restatement of glibc expf. */
+/* f32::exp as used by softmax (functional.rs:133) and SiLU (transformer.rs:617): the device's bit-exact restatement of glibc expf. */
 int lmrs_op_expf(int device, float* y, const float* x, size_t n);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------
@@ -146,7 +147,8 @@ int lmrs_bench_gemv(lmrs_ctx* ctx, int iters, double* us5, double* bytes5, int* 
  * kernel of the last decode step, in launch order: [0..3] first workgroup, [4..7] last workgroup:
  * start, prologue done, first rows done, end. */
 int lmrs_debug_timeline(lmrs_ctx* ctx, unsigned long long* out, int max_nodes, int* n_nodes);
-/* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos`. */
+/* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos` (the byte model of SURVEY.md §8d;
+ * measurement aid, no reference counterpart). */
 int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);
 
 /* ---- CLIP image tower of the multimodal models  (src/vision.rs) ---------------------------

@@ -183,6 +183,11 @@ int lmrs_processor_create(const uint8_t* section, size_t len, int device, lmrs_p
 void lmrs_processor_destroy(lmrs_processor* p);
 int lmrs_processor_forward(lmrs_processor* p, const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t patch_side,
                            uint32_t w_crop, uint32_t h_crop, float* out, uint32_t* n_embeds);
+/* Host-only verification aid (works without a GPU): the rows lmrs_processor_forward feeds to the projector - the HD transform
+ * reshape_hd_patches_2x2merge + add_image_newline (processor.rs:377-418, 480-484) of the sub-images, glb_GN, the same of the
+ * global crop (:240-254) - for given separators.  out: n_embeds * 4096 floats. */
+int lmrs_processor_hd_transform(const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t w_crop, uint32_t h_crop,
+                                const float* glb_gn, const float* sub_gn, float* out, uint32_t* n_embeds);
 
 #ifdef __cplusplus
 }

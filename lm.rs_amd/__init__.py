@@ -30,7 +30,7 @@ EXPORTS = [
     "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
-    "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward",
+    "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform",
 ]
 
 
@@ -95,6 +95,7 @@ def lib():
         L.lmrs_processor_destroy.argtypes = [vp]
         L.lmrs_processor_destroy.restype = None
         L.lmrs_processor_forward.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, C.POINTER(u32)]
+        L.lmrs_processor_hd_transform.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -308,6 +309,16 @@ class VisionTransformer:
             self.close()
         except Exception:
             pass
+
+
+def processor_hd_transform(out_patches: np.ndarray, w_crop: int, h_crop: int, glb_gn: np.ndarray, sub_gn: np.ndarray) -> np.ndarray:
+    """Host-only: the projector's input rows (processor.rs:240-254, 377-418, 480-484) -> float32 [n_embeds, 4096]."""
+    op = np.ascontiguousarray(out_patches, np.float32).reshape(-1)
+    g = np.ascontiguousarray(glb_gn, np.float32).reshape(-1); s_ = np.ascontiguousarray(sub_gn, np.float32).reshape(-1)
+    ne = (h_crop * 12) * (w_crop * 12 + 1) + 12 * 13 + 1
+    out = np.empty(ne * 4096, np.float32); n = C.c_uint32()
+    _chk(lib().lmrs_processor_hd_transform(op.ctypes.data, op.size, 576 * 1024, w_crop, h_crop, g.ctypes.data, s_.ctypes.data, out.ctypes.data, C.byref(n)))
+    return out[: n.value * 4096].reshape(n.value, 4096)
 
 
 class PHI3VProcessor:

@@ -1379,6 +1379,30 @@ static void hd_merge_with_newlines(const float* feat, size_t n_floats, size_t h_
     res.insert(res.end(), merged.begin() + src * out_c, merged.begin() + total * out_c);
 }
 
+// The projector's input rows (processor.rs:240-254): sub-image features, glb_GN, global features - H floats per row
+static void hd_embeddings(const float* out_patches, size_t total_floats, size_t new_shape, size_t w_crop, size_t h_crop,
+                          const float* glb_gn, const float* sub_gn, size_t H, std::vector<float>& emb) {
+    std::vector<float> glob, sub;
+    hd_merge_with_newlines(out_patches, new_shape, 1, 1, sub_gn, glob);
+    hd_merge_with_newlines(out_patches + new_shape, total_floats - new_shape, h_crop, w_crop, sub_gn, sub);
+    emb.clear(); emb.reserve(sub.size() + H + glob.size());
+    emb.insert(emb.end(), sub.begin(), sub.end()); emb.insert(emb.end(), glb_gn, glb_gn + H); emb.insert(emb.end(), glob.begin(), glob.end());
+}
+
+// Host-only verification aid (no device needed): exactly the rows lmrs_processor_forward feeds to the projector, for given
+// separators.  out: n_embeds * 4096 floats; *n_embeds = (h_crop*12)*(w_crop*12+1) + 12*13 + 1.
+extern "C" int lmrs_processor_hd_transform(const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t w_crop, uint32_t h_crop,
+                                           const float* glb_gn, const float* sub_gn, float* out, uint32_t* n_embeds) {
+    if (!out_patches || !glb_gn || !sub_gn || !out) return fail("NULL argument");
+    if (new_shape != 576u * 1024u || w_crop == 0 || h_crop == 0 || (size_t)total_floats != (size_t)new_shape * (1 + (size_t)w_crop * h_crop))
+        return fail("processor: out_patches must hold the global crop and h_crop * w_crop sub-images of 576 x 1024 floats");
+    std::vector<float> emb;
+    hd_embeddings(out_patches, total_floats, new_shape, w_crop, h_crop, glb_gn, sub_gn, 4096, emb);
+    memcpy(out, emb.data(), emb.size() * 4);
+    if (n_embeds) *n_embeds = (uint32_t)(emb.size() / 4096);
+    return 0;
+}
+
 // PHI3VProcessor::forward (processor.rs:234-342).  out_patches: the tower's output (total_floats floats: the global crop first,
 // new_shape floats, then the h_crop x w_crop sub-images); out: num_embeds * text_dim floats; *n_embeds = number of embeddings.
 extern "C" int lmrs_processor_forward(lmrs_processor* p, const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t patch_side,
@@ -1388,11 +1412,8 @@ extern "C" int lmrs_processor_forward(lmrs_processor* p, const float* out_patche
         return fail("processor: out_patches must hold the global crop and h_crop * w_crop sub-images of 576 x 1024 floats (patch_side 12)");
     HIP_OK(hipSetDevice(p->device));
     const size_t H = p->hidden, Tt = p->text;
-    std::vector<float> glob, sub, emb;
-    hd_merge_with_newlines(out_patches, new_shape, 1, 1, p->sub_gn.data(), glob);
-    hd_merge_with_newlines(out_patches + new_shape, (size_t)total_floats - new_shape, h_crop, w_crop, p->sub_gn.data(), sub);
-    emb.reserve(sub.size() + H + glob.size());
-    emb.insert(emb.end(), sub.begin(), sub.end()); emb.insert(emb.end(), p->glb_gn.begin(), p->glb_gn.end()); emb.insert(emb.end(), glob.begin(), glob.end());
+    std::vector<float> emb;
+    hd_embeddings(out_patches, total_floats, new_shape, w_crop, h_crop, p->glb_gn.data(), p->sub_gn.data(), H, emb);
     const size_t ne = emb.size() / H;
     if (ne != (size_t)(h_crop * patch_side) * (w_crop * patch_side + 1) + (size_t)patch_side * (patch_side + 1) + 1) return fail("processor: embedding count");
     if (ne > p->cap) {

@@ -97,3 +97,18 @@ def test_cpp_host_mirror_compiles_and_links_against_the_abi(tmp_path):
                    check=True, capture_output=True)
     for example in ("chat_greedy.cpp", "image_prefill.cpp"):
         subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", os.path.join(ROOT, "lm.rs_amd", "hostcpp", example)], check=True, capture_output=True)
+
+
+@pytest.mark.parametrize("w_crop,h_crop", [(1, 1), (2, 1), (1, 2), (2, 2), (3, 2)])
+def test_processor_hd_transform_on_the_host(w_crop, h_crop):
+    """The host half of lmrs_processor_forward (2x2 HD merge, row separators, glb_GN; processor.rs:240-254, 377-418, 480-484)
+    against the reshape / transpose statement of the same transform in tests/numpy_ref.py - every crop grid, no GPU involved."""
+    import lmrs_amd
+    import numpy_ref as NR
+    rng = np.random.default_rng(w_crop * 10 + h_crop)
+    feats = rng.standard_normal((1 + w_crop * h_crop, 576, 1024)).astype(np.float32)
+    glb = rng.standard_normal(4096).astype(np.float32); sub = rng.standard_normal(4096).astype(np.float32)
+    got = lmrs_amd.processor_hd_transform(feats, w_crop, h_crop, glb, sub)
+    ref = np.concatenate([NR.hd_transform(feats[1:], h_crop, w_crop, sub), glb.reshape(1, -1), NR.hd_transform(feats[:1], 1, 1, sub)])
+    assert got.shape == ref.shape == ((h_crop * 12) * (w_crop * 12 + 1) + 12 * 13 + 1, 4096)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()

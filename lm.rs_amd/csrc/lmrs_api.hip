@@ -67,12 +67,13 @@ struct lmrs_ctx {
     uint32_t* tokens = nullptr; DevState* st = nullptr;
     unsigned long long* dbg = nullptr; int dbg_node = 0;     // LMRS_DEBUG_TIMELINE=1: 8 stamps per kernel node
     // pinned host
-    float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr;
+    float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr; unsigned h_st_next = 0;   // h_st: ring of kStateSlots pinned slots (an async copy may still be reading the previous one)
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
     // long contexts: step graphs whose attention is the split pair, one per context bucket (256-key chunks: 4, 8, 16, 32)
     hipGraphExec_t g_step_long[4] = {nullptr, nullptr, nullptr, nullptr}; float* att_S = nullptr; int att_split_chunks = 0; int att_split_pos = 0;
     // batched forward_layer (fill_kv_cache): device buffers for kPrefillTokens tokens, allocated on first use
     float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr, *pf_t = nullptr; int8_t* pf_xq = nullptr; float* pf_att = nullptr; size_t pf_att_cap = 0;
+    bool pf_ready = false;                                 // every prefill buffer above is allocated
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
@@ -375,9 +376,13 @@ int upload_interleaved(lmrs_ctx* c, void* dst, const uint8_t* src, size_t row_by
     return 0;
 }
 
+// Every call gets its own pinned slot: the copy is asynchronous, so rewriting ONE slot twice inside an API call (the batched
+// fill_kv_cache does) could overtake the first copy.  No API call issues more than a handful between two stream syncs.
+constexpr unsigned kStateSlots = 16;
 int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end, int win_base = -1) {
-    c->h_st->pos = (int)pos; c->h_st->prompt_end = (int)prompt_end; c->h_st->step_count = 0; c->h_st->win_base = win_base;
-    HIP_OK(hipMemcpyAsync(c->st, c->h_st, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
+    DevState* hs = c->h_st + (c->h_st_next++ % kStateSlots);
+    hs->pos = (int)pos; hs->prompt_end = (int)prompt_end; hs->step_count = 0; hs->win_base = win_base;
+    HIP_OK(hipMemcpyAsync(c->st, hs, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
     if (c->flags) {       // in-launch arrival counters and error word start every call from zero
         HIP_OK(hipMemsetAsync(c->flags, 0, (size_t)c->n_flag_words * 4, c->stream));
         HIP_OK(hipMemsetAsync(c->err, 0, 4, c->stream));
@@ -439,7 +444,7 @@ extern "C" int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx
 // exchanged by device-to-device copies instead of RCCL, so that the sharding can be checked bit for bit on a
 // single-GPU box.  shards[] receives `world` contexts; drive them with lmrs_group_forward.
 extern "C" int lmrs_group_create(const uint8_t* file, size_t len, int device, int world, lmrs_ctx** shards, size_t* bytes_consumed) {
-    if (world < 1 || !shards) return fail("bad argument");
+    if (world < 2 || !shards) return fail("a shard group needs world >= 2 (use lmrs_create for one GPU)");
     for (int r = 0; r < world; ++r) shards[r] = nullptr;
     for (int r = 0; r < world; ++r)
         if (create_impl(file, len, device, r, world, nullptr, true, &shards[r], bytes_consumed)) {
@@ -659,7 +664,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     }
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_logits), V * 4, hipHostMallocDefault));
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_tok), ((size_t)a.seq_len + 8) * 4, hipHostMallocDefault));
-    HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_st), sizeof(DevState), hipHostMallocDefault));
+    HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_st), kStateSlots * sizeof(DevState), hipHostMallocDefault));
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_err), 4, hipHostMallocDefault));
     CK(set_state(c, 0, 0));
     HCK(hipStreamSynchronize(c->stream));
@@ -800,17 +805,23 @@ static bool prefill_batched_ok(const lmrs_ctx* c) {
 }
 
 static int prefill_alloc(lmrs_ctx* c) {
-    if (c->pf_x) return 0;
+    if (c->pf_ready) return 0;
     const lmrs_args& a = c->args;
     const size_t B = kPrefillTokens, wide = std::max<size_t>(std::max<size_t>(a.dim, a.hidden_dim), (size_t)c->att_dim);
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_x), B * a.dim * 4));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_q), B * c->att_dim * 4));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_k), B * c->kv_dim * 4));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_ao), B * c->att_dim * 4));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_h), B * a.hidden_dim * 4));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_xq), B * wide));
-    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_xs), B * (wide / 128) * 4));
-    if (a.model_type == LMRS_GEMMA) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_t), B * a.dim * 4));
+    struct Want { void** p; size_t bytes; } want[] = {
+        {reinterpret_cast<void**>(&c->pf_x), B * a.dim * 4}, {reinterpret_cast<void**>(&c->pf_q), B * c->att_dim * 4},
+        {reinterpret_cast<void**>(&c->pf_k), B * c->kv_dim * 4}, {reinterpret_cast<void**>(&c->pf_ao), B * c->att_dim * 4},
+        {reinterpret_cast<void**>(&c->pf_h), B * a.hidden_dim * 4}, {reinterpret_cast<void**>(&c->pf_xq), B * wide},
+        {reinterpret_cast<void**>(&c->pf_xs), B * (wide / 128) * 4}, {reinterpret_cast<void**>(&c->pf_t), a.model_type == LMRS_GEMMA ? B * a.dim * 4 : 0}};
+    for (const Want& w : want) {
+        if (!w.bytes || *w.p) continue;
+        const hipError_t e = hipMalloc(w.p, w.bytes);
+        if (e != hipSuccess) {                       // all or nothing: a half-allocated set must never reach the kernels
+            for (const Want& u : want) if (*u.p) { (void)hipFree(*u.p); *u.p = nullptr; }
+            return fail(std::string("prefill buffers: hipMalloc: ") + hipGetErrorString(e));
+        }
+    }
+    c->pf_ready = true;
     return 0;
 }
 
@@ -1199,7 +1210,7 @@ extern "C" int lmrs_vision_create(const uint8_t* sec, size_t len, int device, lm
     const size_t dim = v->dim, L = v->n_layers, hid = v->hidden, kdim = 3ull * v->patch * v->patch, G = dim / 128, GH = hid / 128;
     const size_t need = 128 + 4 * (dim + dim * kdim + dim * 577 + 8 * L * dim + L * hid + L * dim + 2 * dim) + L * (4 * (dim * dim + dim * G * 4) + 2 * (dim * hid + dim * GH * 4));
     if (len < need) return bad("vision section truncated");
-    HIP_OK(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) return bad("hipStreamCreate failed");
     size_t off = 128;
     auto f32v = [&](size_t count) { const uint8_t* p = sec + off; off += count * 4; return p; };
     v->class_emb = vis_dev<float>(v, f32v(dim), dim * 4);
@@ -1229,9 +1240,10 @@ extern "C" int lmrs_vision_create(const uint8_t* sec, size_t len, int device, lm
         if (!Y.wqkv || !Y.sqkv || !Y.bqkv) return bad("hipMalloc failed");
         const QT* three[3] = {&tq, &tk, &tv};
         for (int w = 0; w < 3; ++w) {
-            HIP_OK(hipMemcpy(Y.wqkv + (size_t)w * dim * dim, three[w]->q[l], dim * dim, hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(Y.sqkv + (size_t)w * dim * G, three[w]->s[l], dim * G * 4, hipMemcpyHostToDevice));
-            HIP_OK(hipMemcpy(Y.bqkv + (size_t)w * dim, three[w]->bias + l * dim * 4, dim * 4, hipMemcpyHostToDevice));
+            if (hipMemcpy(Y.wqkv + (size_t)w * dim * dim, three[w]->q[l], dim * dim, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(Y.sqkv + (size_t)w * dim * G, three[w]->s[l], dim * G * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(Y.bqkv + (size_t)w * dim, three[w]->bias + l * dim * 4, dim * 4, hipMemcpyHostToDevice) != hipSuccess)
+                return bad("upload of the vision weights failed");
         }
         Y.wo = vis_dev<int8_t>(v, to.q[l], dim * dim); Y.so = vis_dev<float>(v, to.s[l], dim * G * 4); Y.bo = vis_dev<float>(v, to.bias + l * dim * 4, dim * 4);
         Y.w1 = vis_dev<int8_t>(v, t1.q[l], hid * dim); Y.s1 = vis_dev<float>(v, t1.s[l], hid * G * 4); Y.b1 = vis_dev<float>(v, t1.bias + l * hid * 4, hid * 4);
@@ -1339,7 +1351,7 @@ extern "C" int lmrs_processor_create(const uint8_t* sec, size_t len, int device,
     const size_t H = p->hidden, Tt = p->text;
     const size_t need = 128 + 4 * (2 * H + 2 * Tt) + (Tt * H + Tt * H / 128 * 4) + (Tt * Tt + Tt * Tt / 128 * 4);
     if (len < need) return bad("processor section truncated");
-    HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return bad("hipStreamCreate failed");
     size_t off = 128;
     p->glb_gn.assign(reinterpret_cast<const float*>(sec + off), reinterpret_cast<const float*>(sec + off) + H); off += H * 4;
     p->sub_gn.assign(reinterpret_cast<const float*>(sec + off), reinterpret_cast<const float*>(sec + off) + H); off += H * 4;

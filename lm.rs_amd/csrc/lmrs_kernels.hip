@@ -228,6 +228,18 @@ __device__ __forceinline__ int group_partial_dot(const i32x4& w, const int8_t* x
     return d;
 }
 
+// sample_argmax (sampler.rs:29-41) starts from probabilities[0] and only moves on a strict `>`: a NaN logit at index 0 is
+// never displaced.  The workgroup that owns global row 0 (block 0 of the launch whose row_offset is 0) reports that case by
+// storing index -1 in its partial; argmax_final_kernel - on every shard, the partials are gathered - then answers 0.
+// (Called by thread 0 after the workgroup's __syncthreads(): the logit was stored by this workgroup and has reached L2.)
+__device__ __forceinline__ int cls_flag_nan_at_zero(const GemvArgs& a, int best_i) {
+    if (blockIdx.x == 0 && a.row_offset == 0) {
+        const float l0 = __hip_atomic_load(a.out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(l0 == l0)) return -1;
+    }
+    return best_i;
+}
+
 // Debug timeline: when a.dbg is set, lane 0 of the first and of the last workgroup record the 100 MHz
 // wall clock at four points (start, prologue done, first pass consumed, end).
 #define LMRS_STAMP(k)                                                                                         \
@@ -424,6 +436,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         if (threadIdx.x == 0) {
             for (int w2 = 1; w2 < kBlock / 64; ++w2)
                 if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
+            best_i = cls_flag_nan_at_zero(a, best_i);
             a.part_val[blockIdx.x] = best; a.part_idx[blockIdx.x] = best_i;
         }
     }
@@ -574,6 +587,7 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
         if (threadIdx.x == 0) {
             for (int w2 = 1; w2 < NTH / 64; ++w2)
                 if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
+            best_i = cls_flag_nan_at_zero(a, best_i);
             a.part_val[blockIdx.x] = best; a.part_idx[blockIdx.x] = best_i;
         }
     }
@@ -1289,14 +1303,16 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
     LMRS_STAMP(0);
     if (a.dbg && threadIdx.x == 0) a.dbg[1] = clock64();          // shader-clock cycles, to derive the running clock
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
+    int nan0 = 0;                                                  // index -1: the logit at index 0 is NaN (cls_flag_nan_at_zero)
     // partials: n_groups shards x n_part entries; shard g holds [values | indices] at part_val + g * group_stride
     for (int i = threadIdx.x; i < a.n_part * a.n_groups; i += kBlock) {
         const int g = i / a.n_part, k = i - g * a.n_part;
         const float v = a.part_val[(size_t)g * a.group_stride + k]; const int idx = a.part_idx[(size_t)g * a.group_stride + k];
+        if (idx < 0) { nan0 = 1; continue; }
         if (v > best || (v == best && idx < best_i)) { best = v; best_i = idx; }
     }
     sv[threadIdx.x] = best; si[threadIdx.x] = best_i;
-    __syncthreads();
+    nan0 = __syncthreads_or(nan0);
     for (int off = kBlock / 2; off >= 1; off >>= 1) {
         if (threadIdx.x < off) {
             const float ov = sv[threadIdx.x + off]; const int oi = si[threadIdx.x + off];
@@ -1306,8 +1322,7 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
     }
     if (threadIdx.x == 0) {
         int win = si[0];
-        const float l0 = a.logits[0];
-        if (!(l0 == l0) || win == 0x7fffffff) win = 0;      // NaN at index 0 is never displaced (strict >)
+        if (nan0 || win == 0x7fffffff) win = 0;             // NaN at index 0 is never displaced (strict >); nothing above -inf: index 0
         const int pos = a.st->pos;
         uint32_t next = (uint32_t)win;
         if (pos + 1 >= a.st->prompt_end) a.tokens[pos + 1] = next;   // chat.rs:188-193: sampler output ignored while the prompt lasts

@@ -133,6 +133,11 @@ int lmrs_op_quantize_q4(int device, uint8_t* q, float* s, const float* x, size_t
 int lmrs_op_rmsnorm(int device, float* o, const float* x, const float* weight, size_t size, float eps, int add_unit_offset);
 /* functional.rs:122-140 (in place) */
 int lmrs_op_softmax(int device, float* x, size_t n);
+/* The decode step's classifier launch + final argmax on caller-supplied rows: final rmsnorm + quantize + matmul_q8 (transformer.rs:341-381)
+ * and Sampler::sample_argmax (sampler.rs:29-41: starts at index 0, moves on a strict `>`: first index of the maximum; a NaN at index 0
+ * is never displaced, NaNs elsewhere never win).  logits (optional): the o logits. */
+int lmrs_op_classifier_argmax(int device, const float* x, const float* rms_w, const int8_t* wq, const float* ws, size_t n, size_t o,
+                              float eps, uint32_t* token, float* logits);
 /* f32::exp as used by softmax (functional.rs:133) and SiLU (transformer.rs:617): the device's bit-exact restatement of glibc expf. */
 int lmrs_op_expf(int device, float* y, const float* x, size_t n);
 
@@ -147,6 +152,9 @@ int lmrs_bench_gemv(lmrs_ctx* ctx, int iters, double* us5, double* bytes5, int* 
  * kernel of the last decode step, in launch order: [0..3] first workgroup, [4..7] last workgroup:
  * start, prologue done, first rows done, end. */
 int lmrs_debug_timeline(lmrs_ctx* ctx, unsigned long long* out, int max_nodes, int* n_nodes);
+/* Verification aid (no reference counterpart; the reference's key_cache / value_cache are private, transformer.rs:302-303): one row of
+ * the KV cache as the reference lays it out (which: 0 key, 1 value; kv_dim floats of `layer` at `pos`). */
+int lmrs_debug_kv(lmrs_ctx* ctx, int which, uint32_t layer, uint32_t pos, float* out);
 /* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos` (the byte model of SURVEY.md §8d;
  * measurement aid, no reference counterpart). */
 int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);

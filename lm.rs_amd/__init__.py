@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform",
@@ -96,6 +96,8 @@ def lib():
         L.lmrs_processor_destroy.restype = None
         L.lmrs_processor_forward.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, C.POINTER(u32)]
         L.lmrs_processor_hd_transform.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, C.POINTER(u32)]
+        L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
+        L.lmrs_op_classifier_argmax.argtypes = [C.c_int, vp, vp, vp, vp, sz, sz, C.c_float, C.POINTER(u32), vp]
         _lib = L
     return _lib
 
@@ -170,6 +172,12 @@ class Transformer:
         sec = C.c_double()
         _chk(lib().lmrs_generate_greedy(self._h, _p(pr), pr.size, n_new, start_pos, _p(out), C.byref(sec)))
         return (out, sec.value) if timing else out
+
+    def kv_row(self, which: int, layer: int, pos: int) -> np.ndarray:
+        """Verification aid: one KV-cache row in the reference's layout (which: 0 key, 1 value)."""
+        out = np.empty(self.args.n_kv_heads * self.args.head_size, np.float32)
+        _chk(lib().lmrs_debug_kv(self._h, which, layer, pos, _p(out)))
+        return out
 
     def shard_uses_graph(self) -> int:
         return lib().lmrs_shard_uses_graph(self._h)
@@ -273,6 +281,16 @@ def softmax(x, device=0):
     x = np.array(x, np.float32, copy=True)
     _chk(lib().lmrs_op_softmax(device, _p(x), x.size))
     return x
+
+
+def classifier_argmax(x, rms_w, wq, ws, eps, device=0):
+    """Final rmsnorm + quantize + matmul_q8 (transformer.rs:341-381) + sample_argmax (sampler.rs:29-41) -> (token, logits)."""
+    x = np.ascontiguousarray(x, np.float32); rms_w = np.ascontiguousarray(rms_w, np.float32)
+    wq = np.ascontiguousarray(wq, np.int8); ws = np.ascontiguousarray(ws, np.float32)
+    n = x.size; o = wq.size // n
+    tok = C.c_uint32(); logits = np.empty(o, np.float32)
+    _chk(lib().lmrs_op_classifier_argmax(device, _p(x), _p(rms_w), _p(wq), _p(ws), n, o, eps, C.byref(tok), _p(logits)))
+    return tok.value, logits
 
 
 def expf(x, device=0):

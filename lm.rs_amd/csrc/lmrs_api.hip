@@ -1032,6 +1032,22 @@ extern "C" int lmrs_debug_timeline(lmrs_ctx* c, unsigned long long* out, int max
     return 0;
 }
 
+// Verification aid (no reference counterpart): one row of the KV cache in the reference's layout (transformer.rs:302-303, 413:
+// kv_dim floats of layer `layer`, position `pos`).  V is stored that way; K is stored blocked for the score lanes
+// ([kv head][head/4][seq_len][4], see attention_body) and is gathered back here.
+extern "C" int lmrs_debug_kv(lmrs_ctx* c, int which, uint32_t layer, uint32_t pos, float* out) {
+    if (!c || !out) return fail("NULL argument");
+    if (which < 0 || which > 1 || layer >= c->args.n_layers || pos >= c->args.seq_len) return fail("bad layer / position");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    const size_t S = c->args.seq_len, hs = c->args.head_size, kv = (size_t)c->kv_dim, nkv = kv / hs;
+    if (which == 1) { HIP_OK(hipMemcpy(out, c->v_cache + ((size_t)layer * S + pos) * kv, kv * 4, hipMemcpyDeviceToHost)); return 0; }
+    const float* kl = c->k_cache + (size_t)layer * nkv * hs * S;
+    for (size_t h = 0; h < nkv; ++h)
+        HIP_OK(hipMemcpy2D(out + h * hs, 16, kl + h * hs * S + pos * 4, S * 16, 16, hs / 4, hipMemcpyDeviceToHost));   // hs/4 words of 4 dims, S*16 bytes apart
+    return 0;
+}
+
 extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, double* algo_bytes) {
     if (!c) return fail("ctx is NULL");
     const lmrs_args& a = c->args;
@@ -1140,6 +1156,37 @@ extern "C" int lmrs_op_softmax(int device, float* x, size_t n) {
     HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
     HIP_OK(launch_softmax(static_cast<float*>(dx), (int)n, nullptr));
     HIP_OK(hipMemcpy(x, dx, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// The classifier launch of the decode step (final rmsnorm + quantise | Q8_0 rows | logits + per-workgroup argmax partials)
+// followed by the final argmax kernel, on caller-supplied rows: transformer.rs:341-381 + Sampler::sample_argmax (sampler.rs:29-41).
+// For the edge cases the whole-model tests cannot reach (ties, NaN at index 0, NaN elsewhere, nothing above -inf).
+extern "C" int lmrs_op_classifier_argmax(int device, const float* x, const float* rms_w, const int8_t* wq, const float* ws, size_t n, size_t o,
+                                         float eps, uint32_t* token, float* logits) {
+    if (op_begin(device)) return -1;
+    if (!x || !rms_w || !wq || !ws || !token) return fail("NULL argument");
+    if (n % 256 || n == 0 || n > 10240 || o == 0 || o % 4) return fail("n must be a multiple of 256 (<= 10240) and o a multiple of 4");
+    Scratch S; const size_t G = n / 128;
+    void *dx = S.get(n * 4), *dw = S.get(n * 4), *dq = S.get(o * n), *ds = S.get(o * G * 4), *dl = S.get(o * 4), *pv = S.get(kMaxArgmaxParts * 4), *pi = S.get(kMaxArgmaxParts * 4);
+    void *dtok = S.get(16), *dst = S.get(sizeof(DevState));
+    if (!dst) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dw, rms_w, n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dq, wq, o * n, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(ds, ws, o * G * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(dtok, 0, 16)); HIP_OK(hipMemset(dst, 0, sizeof(DevState)));
+    GemvArgs g{};
+    g.wq = dq; g.ws = static_cast<float*>(ds); g.n = (int)n; g.o = (int)o; g.xin = static_cast<float*>(dx); g.rms_w = static_cast<float*>(dw); g.eps = eps;
+    g.out = static_cast<float*>(dl); g.part_val = static_cast<float*>(pv); g.part_idx = static_cast<int*>(pi); g.st = static_cast<DevState*>(dst);
+    const int grid = gemv_grid(g, PRO_RMS_QUANT, EPI_CLS);
+    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, nullptr));
+    ArgmaxArgs m{};
+    m.part_val = g.part_val; m.part_idx = g.part_idx; m.n_part = grid; m.n_groups = 1; m.logits = g.out; m.tokens = static_cast<uint32_t*>(dtok); m.st = static_cast<DevState*>(dst);
+    m.emb.dim = 0;                                      // no embedding row to prepare
+    HIP_OK(launch_argmax_final(m, nullptr));
+    uint32_t tk[2];
+    HIP_OK(hipMemcpy(tk, dtok, 8, hipMemcpyDeviceToHost));
+    *token = tk[1];                                     // tokens[pos + 1] with pos = 0, prompt_end = 0
+    if (logits) HIP_OK(hipMemcpy(logits, dl, o * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -188,9 +188,10 @@ def test_mini_models_logits_bit_exact(L, cfg):
         assert_bit_equal(lg, lo, f"{cfg} logits at pos {pos}")
         tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
         assert m.forward_argmax(t, pos) == tok        # re-running a position is idempotent
-    for l in range(2):                                 # KV cache rows identical too
-        kv = m.args.n_kv_heads * m.args.head_size
-        assert kv == orc.args.n_kv_heads * orc.args.head_size
+    for l in range(m.args.n_layers):                   # the KV cache rows behind those logits, every layer, first / middle / last position
+        for pos in (0, 7, 19):
+            for which, nm in ((0, "key"), (1, "value")):
+                assert_bit_equal(m.kv_row(which, l, pos), orc.kv_row(which, l, pos), f"{cfg} {nm} row, layer {l}, pos {pos}")
 
 
 @pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q4_0), ("mini-gemma", S.Q4_0), ("mini-gemma", S.Q8_0), ("mini-gemma9b", S.Q8_0), ("tiny-wide-att", S.Q4_0)])
@@ -297,6 +298,45 @@ def test_get_embeddings_and_fill_kv_cache(L, cfg, q):
     assert_bit_equal(m.forward(5, 12), orc.forward(5, 12), "decode after fill_kv_cache")
 
 
+# ------------------------------------------------------------------ sample_argmax edge cases (sampler.rs:29-41)
+def _cls_case(rows_scale, rows_k, n=256):
+    """One activation spike in group 0 -> logit[r] = ((127 * k_r) as f32 * ws[r][0]) * xs[0] (+ an exact zero from group 1): any
+    float - NaN, +-inf, ties - can be placed at any row through ws."""
+    o = len(rows_scale)
+    x = np.zeros(n, np.float32); x[0] = 3.0
+    w = np.ones(n, np.float32)
+    wq = np.zeros((o, n), np.int8); wq[:, 0] = rows_k
+    ws = np.ones((o, n // 128), np.float32); ws[:, 0] = rows_scale
+    return x, w, wq, ws
+
+
+@pytest.mark.parametrize("case", ["tie_first_wins", "nan_at_zero", "nan_elsewhere", "all_minus_inf", "max_in_last_row", "tie_across_workgroups", "plus_inf_tie"])
+def test_argmax_edge_cases(L, case):
+    """Transformer::forward's classifier + Sampler::sample_argmax as the decode step runs them (EPI_CLS partials + argmax_final):
+    the reference starts at index 0 and moves on a strict `>` - first index of the maximum, a NaN at index 0 is never displaced,
+    NaNs elsewhere never win, a row of -inf answers 0."""
+    o = 4096
+    rng = np.random.default_rng(3)
+    sc = rng.uniform(0.5, 1.5, o).astype(np.float32); k = rng.integers(-100, 100, o).astype(np.int8)
+    if case == "tie_first_wins": sc[:] = 1.0; k[:] = 5; k[[77, 900, 3000]] = 120
+    elif case == "nan_at_zero": sc[0] = np.nan; k[0] = 1
+    elif case == "nan_elsewhere": sc[[5, 2047, 4095]] = np.nan; k[[5, 2047, 4095]] = 1; sc[1234] = 9.0; k[1234] = 127
+    elif case == "all_minus_inf": sc[:] = -np.inf; k[:] = 1
+    elif case == "max_in_last_row": sc[o - 1] = 50.0; k[o - 1] = 127
+    elif case == "tie_across_workgroups": sc[:] = 1.0; k[:] = -3; k[[2500, 40]] = 99
+    elif case == "plus_inf_tie": sc[[3000, 17]] = np.inf; k[[3000, 17]] = 1
+    x, w, wq, ws = _cls_case(sc, k)
+    tok, lg = L.classifier_argmax(x, w, wq, ws, 1e-5)
+    xq, xs = O.quantize(O.rmsnorm(x, w, 1e-5))
+    ref = O.matmul_q8(xq, xs, wq.reshape(-1), ws.reshape(-1), x.size, o)
+    assert_bit_equal(lg, ref, f"{case}: logits")
+    want = int(O.lib().lmrs_ref_argmax(ref.ctypes.data, ref.size))
+    assert tok == want, f"{case}: device {tok}, reference {want} (logit[tok] = {ref[tok]}, logit[want] = {ref[want]})"
+    expect = {"tie_first_wins": 77, "nan_at_zero": 0, "nan_elsewhere": 1234, "all_minus_inf": 0, "max_in_last_row": o - 1,
+              "tie_across_workgroups": 40, "plus_inf_tie": 17}[case]
+    assert want == expect, f"{case}: the oracle itself answered {want}, the reference's rule gives {expect}"
+
+
 # ------------------------------------------------------------------ BASELINE config 2 at full size
 def test_llama_1b_q8_greedy_token_ids(L):
     """BASELINE.json configs[0]/[1]: Llama-3.2-1B Q8_0, greedy, 16-token prompt + 128 generated tokens;
@@ -329,6 +369,26 @@ def test_llama_1b_q8_long_prompt_at_full_size(L):
     assert (got == ref).all(), f"first mismatch at {int(np.flatnonzero(got != ref)[0])}"
     pos = 600 + 39
     assert_bit_equal(m.forward(int(ref[-1]), pos), orc.forward(int(ref[-1]), pos), f"1B logits at pos {pos}")
+
+
+@pytest.mark.parametrize("cfg", ["llama-3.2-3b", "phi-3.5"])
+def test_full_size_3b_and_phi_q8_greedy_token_ids(L, cfg):
+    """BASELINE.json configs[3] (Llama-3.2-3B, 28 layers, on one GPU) and configs[4]'s text model (Phi-3.5, 32 layers, LongRoPE
+    factors, separate lm_head) at FULL size, Q8_0: 16 prompt tokens + 32 greedy tokens identical to the CPU path, the logits of
+    one more step bit-equal, and KV rows of the first / last layer."""
+    img = S.build_image(cfg, S.Q8_0, seed=2024)
+    prompt = S.prompt_tokens(cfg, 16, 2024)
+    m = L.Transformer(img)
+    got, sec = m.generate_greedy(prompt, 32, timing=True)
+    orc = O.Oracle(img)
+    ref = orc.generate_greedy(prompt, 32)
+    assert (got == ref).all(), f"{cfg}: first mismatch at {int(np.flatnonzero(got != ref)[0])}"
+    pos = 16 + 31
+    assert_bit_equal(m.forward(int(ref[-1]), pos), orc.forward(int(ref[-1]), pos), f"{cfg} logits at pos {pos}")
+    for l in (0, m.args.n_layers - 1):
+        for which in (0, 1):
+            assert_bit_equal(m.kv_row(which, l, pos), orc.kv_row(which, l, pos), f"{cfg} kv[{which}] layer {l} pos {pos}")
+    print(f"\n{cfg} q8_0 full size: {47 / sec:.0f} tok/s")
 
 
 def test_gemma_2b_q4_greedy_token_ids(L):
@@ -452,6 +512,98 @@ def test_vision_tower_matches_the_cpu_path(L, n_layers, num_crops):
     pv = V.pixel_values(cfg, num_crops, seed=3)
     got = dev.forward(pv, num_crops); ref = orc.forward(pv, num_crops)
     assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"vision tower, {n_layers - 1} layer(s), {num_crops} crop(s)")
+
+
+def test_vision_tower_at_full_depth(L):
+    """The tower as configs[4] runs it: 24 layers in the file, 23 executed (vision.rs:303), global crop + one sub-image."""
+    from tools import synth_vision as V
+    cfg = V.VisionCfg(n_layers=24)
+    sec = V.build_vision_section(cfg, seed=41)
+    dev = L.VisionTransformer(sec); orc = O.VisionOracle(sec)
+    pv = V.pixel_values(cfg, 2, seed=6)
+    assert_bit_equal(dev.forward(pv, 2).reshape(-1), orc.forward(pv, 2).reshape(-1), "vision tower, 23 layers, 2 crops")
+
+
+def _multimodal_file(text_cfg, vis_layers, seed):
+    from tools import synth_vision as V
+    text = S.build_image(text_cfg, S.Q8_0, seed=seed, multimodal=1)
+    vcfg = V.VisionCfg(n_layers=vis_layers)
+    return np.concatenate([text, V.build_vision_section(vcfg, seed=seed + 1), V.build_processor_section(seed=seed + 2)]), vcfg
+
+
+def _image_prefill(model, vision, processor, pv, num_crops, w_crop, h_crop, bos_image, bos_text):
+    """chat.rs:84-121: vision.forward -> processor.forward -> [prefix embeddings | image features | suffix embeddings] -> fill_kv_cache."""
+    feats = vision.forward(pv, num_crops)
+    img = processor.forward(feats, 576 * 1024, 336 // 14 // 2, w_crop, h_crop)
+    pre = model.get_embeddings(np.asarray(bos_image, np.uint32)); suf = model.get_embeddings(np.asarray(bos_text, np.uint32))
+    emb = np.ascontiguousarray(np.concatenate([pre.reshape(-1), img.reshape(-1), suf.reshape(-1)]), np.float32)
+    return emb, model.fill_kv_cache(emb, 0), img
+
+
+@pytest.mark.parametrize("text_cfg,vis_layers", [("mini-phi-long", 3), ("phi-3.5", 24)])
+def test_multimodal_prefill_end_to_end(L, text_cfg, vis_layers):
+    """BASELINE.json configs[4] in the reference's call order (src/bin/chat.rs:84-121): Transformer::new, VisionTransformer::new at
+    the offset it returned, PHI3VProcessor::new after the vision section; vision.forward -> processor.forward -> the 313 image
+    features spliced between two get_embeddings blocks (4 + 313 + 3 = 320 embeddings) -> fill_kv_cache(320) -> 8 greedy decode
+    steps on the prefilled cache.  Every stage bit-equal to the CPU path: image features, the mutated embeddings, the token ids,
+    the logits of one more step and KV rows inside the image span.  ("phi-3.5", 24): everything at full size."""
+    from tools import synth_vision as V
+    data, vcfg = _multimodal_file(text_cfg, vis_layers, seed=31)
+    m = L.Transformer(data); orc = O.Oracle(data)
+    assert m.args.multimodal == 1 and m.bytes_consumed == orc.bytes_consumed
+    off = m.bytes_consumed
+    vis = L.VisionTransformer(data[off:]); vis_o = O.VisionOracle(data[off:])
+    proc = L.PHI3VProcessor(data[off + vis.bytes_consumed:]); proc_o = O.ProcessorOracle(data[off + vis_o.bytes_consumed:])
+    assert off + vis.bytes_consumed + proc.bytes_consumed == data.size
+    pv = V.pixel_values(vcfg, 2, seed=8)
+    V_ = m.args.vocab_size
+    bos_image = [1, 32010 % V_, 29871 % V_, 13]; bos_text = [1, 29871 % V_, 13]          # chat.rs:110-112 (ids folded into the mini vocabulary)
+    e_dev, p_dev, f_dev = _image_prefill(m, vis, proc, pv, 2, 1, 1, bos_image, bos_text)
+    e_ref, p_ref, f_ref = _image_prefill(orc, vis_o, proc_o, pv, 2, 1, 1, bos_image, bos_text)
+    assert f_dev.shape == (313, 3072) and p_dev == p_ref == 320
+    assert_bit_equal(f_dev.reshape(-1), f_ref.reshape(-1), "image features")
+    assert_bit_equal(e_dev, e_ref, "embeddings after fill_kv_cache")
+    prompt = S.prompt_tokens(text_cfg, 5, 77)
+    got = m.generate_greedy(prompt, 8, start_pos=320); ref = orc.generate_greedy(prompt, 8, start_pos=320)
+    assert (got == ref).all(), (got, ref)
+    pos = 320 + 5 + 7
+    assert_bit_equal(m.forward(int(ref[-1]), pos), orc.forward(int(ref[-1]), pos), f"logits at pos {pos}")
+    for l in (0, m.args.n_layers - 1):
+        for p in (3, 160, 319, pos):
+            for which in (0, 1):
+                assert_bit_equal(m.kv_row(which, l, p), orc.kv_row(which, l, p), f"kv[{which}] layer {l} pos {p}")
+
+
+def test_image_prefill_host_program_runs_on_the_gpu(L, tmp_path):
+    """hostcpp/image_prefill.cpp - the same call order through the C++ mirrors of Transformer / VisionTransformer / PHI3VProcessor -
+    built with g++ against the shared library and RUN: its token ids equal the Python path's (and therefore the CPU path's)."""
+    import subprocess
+    from tools import synth_vision as V
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "lm.rs_amd", "hostcpp")
+    exe = str(tmp_path / "image_prefill")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(host, "image_prefill.cpp"), "-I", os.path.join(root, "include"),
+                    "-L", os.path.join(root, "lm.rs_amd"), "-llmrs_hip", f"-Wl,-rpath,{os.path.join(root, 'lm.rs_amd')}", "-o", exe], check=True)
+    # the program feeds the reference's literal prefix / suffix ids (chat.rs:110-112): needs the real vocabulary size, few layers
+    cfg = S.ModelCfg("phi-2layer", 3072, 8192, 2, 32, 96, 32, 32064, 131072, 1e-5, 10000.0, S.PHI)
+    text = S.build_image(cfg, S.Q8_0, seed=57, multimodal=1)
+    vcfg = V.VisionCfg(n_layers=3)
+    data = np.concatenate([text, V.build_vision_section(vcfg, seed=58), V.build_processor_section(seed=59)])
+    pv = V.pixel_values(vcfg, 2, seed=9)
+    data.tofile(tmp_path / "model.lmrs"); np.ascontiguousarray(pv, np.float32).tofile(tmp_path / "patches.f32")
+    prompt = [int(t) for t in S.prompt_tokens(cfg, 5, 12)]
+    out = subprocess.run([exe, str(tmp_path / "model.lmrs"), str(tmp_path / "patches.f32"), "2", "1", "1", "8"] + [str(t) for t in prompt],
+                         check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert "313 embeddings" in out[0] and "position 320" in out[0], out
+    ids_cpp = np.array([int(t) for t in out[1].split()], np.uint32)
+    m = L.Transformer(data); off = m.bytes_consumed
+    vis = L.VisionTransformer(data[off:]); proc = L.PHI3VProcessor(data[off + vis.bytes_consumed:])
+    _image_prefill(m, vis, proc, pv, 2, 1, 1, [1, 32010, 29871, 13], [1, 29871, 13])
+    ids_py = m.generate_greedy(np.asarray(prompt, np.uint32), 8, start_pos=320)
+    assert (ids_cpp == ids_py).all(), (ids_cpp, ids_py)
+    orc = O.Oracle(data); vo = O.VisionOracle(data[off:]); po = O.ProcessorOracle(data[off + vo.bytes_consumed:])
+    _image_prefill(orc, vo, po, pv, 2, 1, 1, [1, 32010, 29871, 13], [1, 29871, 13])
+    assert (orc.generate_greedy(np.asarray(prompt, np.uint32), 8, start_pos=320) == ids_cpp).all()
 
 
 @pytest.mark.parametrize("w_crop,h_crop", [(1, 1), (2, 1)])

@@ -172,8 +172,9 @@ def image_size(cfg: ModelCfg, q_type: int, gs: int = 128) -> int:
     return n
 
 
-def build_image(cfg: ModelCfg | str, q_type: int = Q8_0, seed: int = 1234, gs: int = 128, threads: int | None = None) -> np.ndarray:
-    """Returns the whole LMRS image as a uint8 array (pass .ctypes.data / len to lmrs_create)."""
+def build_image(cfg: ModelCfg | str, q_type: int = Q8_0, seed: int = 1234, gs: int = 128, threads: int | None = None, multimodal: int = 0) -> np.ndarray:
+    """Returns the whole LMRS image as a uint8 array (pass .ctypes.data / len to lmrs_create).
+    multimodal = 1 sets the header flag (export.py:84); the vision and processor sections (tools/synth_vision.py) follow the image."""
     if isinstance(cfg, str):
         cfg = CONFIGS[cfg]
     if q_type != Q_NONE:
@@ -182,7 +183,7 @@ def build_image(cfg: ModelCfg | str, q_type: int = Q8_0, seed: int = 1234, gs: i
         assert gs == 128 or cfg.dim % 128 != 0, "the reference always quantises with 128 (utils/io.py:21)"
     total = image_size(cfg, q_type, gs)
     img = np.zeros(total, np.uint8)
-    img[:256] = np.frombuffer(header_bytes(cfg, q_type, gs), np.uint8)
+    img[:256] = np.frombuffer(header_bytes(cfg, q_type, gs, multimodal), np.uint8)
 
     tasks = []   # (fam_idx, layer, row0, rows, q_off, s_off)
     off = 256

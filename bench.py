@@ -12,11 +12,15 @@ Weights, KV cache and every activation are resident in HBM when the timed region
 leave the device between steps.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the dominant kernel (the fused Q8_0 dequant-GEMV, lmrs::gemv_kernel<...>): algorithmic bytes
-                (int8 weights + f32 group scales) of one decode step's 81 GEMV launches / their summed
-                durations, each measured live with HIP events on the library's stream (lmrs_bench_gemv),
-                against the 8 TB/s HBM3E peak.  `path` carries the whole-step figure (SURVEY.md §8d bytes
-                per token / measured time per token).
+  roofline      the dominant kernel family (the fused Q8_0 dequant-GEMV, lmrs::gemv_static_kernel<...>): algorithmic
+                bytes (int8 weights + f32 group scales) of one decode step's 65 GEMV launches / their summed
+                durations AS THEY RUN INSIDE THE STEP: the real step (same launches as the captured graph, live
+                activations and positions) is replayed eagerly with a HIP event pair on every dispatch
+                (lmrs_bench_step), against the 8 TB/s HBM3E peak; `frac_vs_measured_copy` prices the same figure
+                against the 6.29 TB/s the chip sustains on a device copy.  `in_step` lists every kernel of the step
+                (attention and argmax included); `path` is the whole-step figure (SURVEY.md §8d bytes per token /
+                measured time per token).  `traffic` comes from a committed rocprofv3 PMC summary and is null
+                unless that summary was taken for this model, quantisation and build of the kernels.
   cpu_baseline  the CPU oracle (a C port of the reference's arithmetic, oracle/lmrs_oracle.c; the Rust
                 reference itself cannot be built here) timed on this box's host cores on the same prompt.
                 The same run is the parity gate: the K token ids must be identical.
@@ -36,6 +40,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MEASURED_COPY_GBPS = 6290.0     # what the chip sustains on a device copy (same guide: "~6.3 TB/s achievable")
 
 
 def exchange_unique_id(dist, rank, make_id):
@@ -48,22 +53,37 @@ def exchange_unique_id(dist, rank, make_id):
     return bytes(uid)
 
 
-def pmc_traffic(n_gemv_per_step):
-    """HBM bytes per GEMV launch from the committed rocprofv3 PMC passes of this same command (profiles/r1_traffic.json,
-    made by tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md applied).
-    bench.py cannot collect hardware counters itself, so this is null when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    try:
-        k = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    per_step = 0
-    for name, v in k.items():
-        if "gemv" in name:
-            # per step: 16 launches of each layer GEMV, 1 classifier launch; weight each kernel by its share of launches
-            per_step += v["hbm_bytes_per_launch"] * v["launches"]
-    n = sum(v["launches"] for name, v in k.items() if "gemv" in name)
-    return round(per_step / n) if n else None
+def kernel_source_hash():
+    """Identifies the build of the kernels: sha256 over the sources liblmrs_hip.so is made from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lm.rs_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(model, qtype):
+    """HBM bytes per GEMV launch from a committed rocprofv3 PMC summary of this same command (profiles/*_traffic*.json, made by
+    tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md applied).  bench.py cannot
+    collect hardware counters itself: the figure is reported only when a summary exists for THIS model, quantisation and build of
+    the kernels (source hash); otherwise null."""
+    want = (model, qtype, kernel_source_hash())
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if "traffic" not in f or not f.endswith(".json"):
+            continue
+        try:
+            doc = json.load(open(os.path.join(pdir, f)))
+            if (doc.get("model"), doc.get("qtype"), doc.get("kernel_source_hash")) != want:
+                continue
+            k = {n: v for n, v in doc["kernels"].items() if "gemv" in n}
+            n = sum(v["launches"] for v in k.values())
+            return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in k.values()) / n) if n else None
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def max_over_ranks(dist, seconds, device=None):
@@ -118,6 +138,7 @@ def main():
 
     import lmrs_amd
     from tools import synth_lmrs as S
+    lmrs_amd.build()                       # (re)compile liblmrs_hip.so if it is missing or older than its sources (a fresh clone has none)
 
     cfg = S.CONFIGS[args.model]
     K, W = args.steps, max(1, args.warmup)
@@ -164,19 +185,24 @@ def main():
                         "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": path["frac"], "traffic": None, "path": path,
                         "sharded_step_is_one_hipgraph": model.shard_uses_graph()}
         else:
-          iters = 5
-          res = model.bench_gemv(iters)
-          per, tot_us, tot_b, n_gemv = {}, 0.0, 0.0, 0
+          # the real step, replayed eagerly from the live state with an event pair on every dispatch: each kernel's
+          # duration as it runs inside the step (real predecessor, real activations, positions W+K+1 ...)
+          iters = 8
+          res = model.bench_step(W + K, iters)
+          per, tot_us, tot_b, n_gemv, step_us = {}, 0.0, 0.0, 0, 0.0
           for name, (us, b, n) in res.items():
             per[name] = {"us": round(us / n, 3), "MB": round(b / n / 1e6, 3), "GBps": round(b / us / 1e3, 1), "launches_per_step": n // iters}
-            tot_us += us / iters; tot_b += b / iters; n_gemv += n // iters
+            step_us += us / iters
+            if name not in ("attention", "argmax"):
+              tot_us += us / iters; tot_b += b / iters; n_gemv += n // iters
           achieved = tot_b / tot_us / 1e3            # GB/s
           roofline = {
-            "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel (fused dequant-GEMV, all shapes of one step)",
+            "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel (fused dequant-GEMV, all shapes of one step), durations taken inside the real step",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": pmc_traffic(n_gemv),
+            "frac_vs_measured_copy": round(achieved / MEASURED_COPY_GBPS, 4),
+            "traffic": pmc_traffic(cfg.name, args.qtype),
             "bytes_per_launch_avg": round(tot_b / n_gemv), "avg_launch_us": round(tot_us / n_gemv, 3), "launches_per_step": n_gemv,
-            "per_shape": per,
+            "in_step": per, "sum_of_kernel_us_per_step": round(step_us, 2), "kernel_source_hash": kernel_source_hash(),
             "path": path,
           }
         # ---- CPU baseline + parity gate

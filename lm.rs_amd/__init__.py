@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform",
@@ -97,6 +97,7 @@ def lib():
         L.lmrs_processor_forward.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, C.POINTER(u32)]
         L.lmrs_processor_hd_transform.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, C.POINTER(u32)]
         L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
+        L.lmrs_bench_step.argtypes = [vp, u32, C.c_int, vp, vp, vp]
         L.lmrs_op_classifier_argmax.argtypes = [C.c_int, vp, vp, vp, vp, sz, sz, C.c_float, C.POINTER(u32), vp]
         _lib = L
     return _lib
@@ -189,6 +190,13 @@ class Transformer:
         _chk(lib().lmrs_bench_gemv(self._h, iters, us, b, n))
         names = ["qkv", "wo", "w1w3", "w2", "classifier"]
         return {names[k]: (us[k], b[k], n[k]) for k in range(5)}
+
+    def bench_step(self, pos: int, iters: int = 8):
+        """Per-kernel durations of the real decode step (eager replay with events on every dispatch) -> {kind: (us, bytes, launches)}."""
+        us = np.zeros(7, np.float64); b = np.zeros(7, np.float64); n = np.zeros(7, np.int32)
+        _chk(lib().lmrs_bench_step(self._h, pos, iters, _p(us), _p(b), _p(n)))
+        names = ("qkv", "attention", "wo", "w1w3", "w2", "classifier", "argmax")
+        return {k: (float(us[i]), float(b[i]), int(n[i])) for i, k in enumerate(names)}
 
     def debug_timeline(self):
         """-> uint64[n_kernels, 8] wall-clock stamps (10 ns units) of the last decode step (needs LMRS_DEBUG_TIMELINE=1)."""

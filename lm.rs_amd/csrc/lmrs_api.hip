@@ -1019,6 +1019,47 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
     return 0;
 }
 
+// The REAL decode step (the launches of the captured graph, in order, on the live state: real activations, real positions)
+// replayed eagerly `iters` times with a (start, stop) event pair on every dispatch: the duration of each kernel of the step as it
+// runs inside the step - after its real predecessor, on the real data.  Decoding continues from the context's current state:
+// call it right after lmrs_generate_greedy; the tokens it produces are valid greedy tokens (and are discarded).
+// kind: 0 qkv, 1 attention, 2 wo, 3 w1w3, 4 w2, 5 classifier, 6 argmax (+ next embedding row).
+extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us7, double* bytes7, int* count7) {
+    if (!c || iters <= 0 || !us7 || !bytes7 || !count7) return fail("bad argument");
+    if (c->world > 1 || c->comm || !c->g_step || c->fused_cls) return fail("lmrs_bench_step: single-GPU contexts (default launch structure) only");
+    if ((size_t)pos + iters + 1 > c->args.seq_len) return fail("positions out of range");
+    if (c->gemma_fused == false && c->args.model_type == LMRS_GEMMA) return fail("lmrs_bench_step: the unfused Gemma form has extra launches");
+    if (c->att_split_pos > 0 && (int)(pos + iters + 1) > c->att_split_pos) return fail("lmrs_bench_step: positions below the split-attention threshold only");
+    HIP_OK(hipSetDevice(c->device));
+    const lmrs_args& a = c->args;
+    const int nl = (int)a.n_layers, per_step = 5 * nl + 2;
+    std::vector<hipEvent_t> ev(2 * (size_t)per_step);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    for (int k = 0; k < 7; ++k) { us7[k] = 0; bytes7[k] = 0; count7[k] = 0; }
+    const double bpe = c->q4 ? 0.5 : 1.0, sc = bpe + 4.0 / 128.0, dim = a.dim, att = c->att_dim, kv = c->kv_dim, hid = a.hidden_dim, V = a.vocab_size;
+    const double wbytes[7] = {dim * (att + 2 * kv) * sc, 0, att * dim * sc, 2 * dim * hid * sc, hid * dim * sc, V * dim * sc, 0};
+    if (set_state(c, pos, 0)) return -1;
+    int rc = 0;
+    for (int it = -1; it < iters && !rc; ++it) {           // it == -1: untimed (the first eager launches pay one-off costs)
+        set_launch_event_pool(ev.data(), per_step);
+        rc = enqueue_step(c);
+        const int used = launch_event_pool_used();
+        set_launch_event_pool(nullptr, 0);
+        if (rc) break;
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (used != per_step) { rc = fail("lmrs_bench_step: the step did not have the expected number of launches"); break; }
+        if (it < 0) continue;                                            // the untimed pass was position `pos`; the timed ones follow it
+        for (int i = 0; i < per_step; ++i) {
+            float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            const int kind = i < 5 * nl ? i % 5 : (i == 5 * nl ? 5 : 6);
+            us7[kind] += (double)ms * 1e3; count7[kind] += 1;
+            bytes7[kind] += kind == 1 ? 2.0 * kv * 4 * ((double)pos + it + 3) : wbytes[kind];     // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
 // Debug timeline (LMRS_DEBUG_TIMELINE=1 at lmrs_create): 8 stamps (100 MHz wall clock) per kernel node of the
 // last replay of the step graph: [0..3] first workgroup, [4..7] last workgroup: start, prologue done, first pass, end.
 extern "C" int lmrs_debug_timeline(lmrs_ctx* c, unsigned long long* out, int max_nodes, int* n_nodes) {

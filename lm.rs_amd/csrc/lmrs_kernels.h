@@ -76,6 +76,8 @@ struct ArgmaxArgs {
 // launches (all asynchronous on `s`)
 hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint = 0);
 void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop);   // measurement: attach events to the next GEMV dispatches (null: off)
+void set_launch_event_pool(hipEvent_t* pairs, int n_pairs);       // measurement: (start, stop) pairs for every following launch, in launch order (null: off)
+int launch_event_pool_used();
 int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
 bool gemv_is_static(const GemvArgs& a, int pro, int epi); // a compile-time-shape kernel exists for this launch
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);

@@ -646,11 +646,23 @@ bool gemv_is_static(const GemvArgs& a, int pro, int epi) { return static_class(a
 // that hipEventElapsedTime(start, stop) is that kernel's begin->end time, the same interval rocprofv3 reports.
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop) { t_ev_start = start; t_ev_stop = stop; }
-#define LMRS_LAUNCH_NT(kern, grid, nt, smem, s, a)                                                          \
+// ... or a pool of (start, stop) pairs handed out to EVERY launch of the decode step in launch order (GEMVs, attention, argmax):
+// an eager replay of the real step then yields the duration of each of its kernels (lmrs_bench_step).
+static thread_local hipEvent_t* t_ev_pool = nullptr; static thread_local int t_ev_cap = 0, t_ev_used = 0;
+void set_launch_event_pool(hipEvent_t* pairs, int n_pairs) { t_ev_pool = pairs; t_ev_cap = n_pairs; t_ev_used = 0; }
+int launch_event_pool_used() { return t_ev_used; }
+static bool next_launch_events(hipEvent_t* a, hipEvent_t* b) {
+    if (t_ev_pool && t_ev_used < t_ev_cap) { *a = t_ev_pool[2 * t_ev_used]; *b = t_ev_pool[2 * t_ev_used + 1]; ++t_ev_used; return true; }
+    if (t_ev_start) { *a = t_ev_start; *b = t_ev_stop; return true; }
+    return false;
+}
+#define LMRS_LAUNCH_GRID(kern, grid3, nt, smem, s, ...)                                                     \
     do {                                                                                                    \
-        if (t_ev_start) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(nt), smem, s, t_ev_start, t_ev_stop, 0, a); \
-        else hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), smem, s, a);                                    \
+        hipEvent_t ea_, eb_;                                                                                \
+        if (next_launch_events(&ea_, &eb_)) hipExtLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, ea_, eb_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, __VA_ARGS__);                               \
     } while (0)
+#define LMRS_LAUNCH_NT(kern, grid, nt, smem, s, a) LMRS_LAUNCH_GRID(kern, dim3(grid), nt, smem, s, a)
 #define LMRS_LAUNCH(kern, grid, smem, s, a) LMRS_LAUNCH_NT(kern, grid, kBlock, smem, s, a)
 
 // Kernels that ask for more than 64 KB of dynamic LDS need the attribute once per (function, device).
@@ -1102,7 +1114,7 @@ int attention_chunk(int head_size) {
 template <int HS, bool GEMMA>
 static hipError_t launch_attention_hsg(const AttnArgs& a, size_t smem, hipStream_t s) {
     allow_big_lds(reinterpret_cast<const void*>(attention_kernel<HS, GEMMA>));
-    hipLaunchKernelGGL((attention_kernel<HS, GEMMA>), dim3(a.n_heads), dim3(kBlock), smem, s, a);
+    LMRS_LAUNCH_GRID((attention_kernel<HS, GEMMA>), dim3(a.n_heads), kBlock, smem, s, a);
     return hipGetLastError();
 }
 template <int HS>
@@ -1246,8 +1258,8 @@ static hipError_t launch_attention_split_hsg(const AttnArgs& a0, float* S, int n
     if (a.chunk * (HP / 4) > kAttF4 * kBlock) return hipErrorInvalidValue;
     const size_t smem = (size_t)(16 + (size_t)(a.chunk + 32) * (HP + 4) + ((a.seq_len + 3) & ~3) + 64) * 4;
     allow_big_lds(reinterpret_cast<const void*>(attention_split_values_kernel<HS, GEMMA>));
-    hipLaunchKernelGGL((attention_split_scores_kernel<HS, GEMMA>), dim3(a.n_heads, n_key_chunks), dim3(kBlock), 0, s, a, S);
-    hipLaunchKernelGGL((attention_split_values_kernel<HS, GEMMA>), dim3(a.n_heads, kAttSplitDims), dim3(kBlock), smem, s, a, (const float*)S);
+    LMRS_LAUNCH_GRID((attention_split_scores_kernel<HS, GEMMA>), dim3(a.n_heads, n_key_chunks), kBlock, 0, s, a, S);
+    LMRS_LAUNCH_GRID((attention_split_values_kernel<HS, GEMMA>), dim3(a.n_heads, kAttSplitDims), kBlock, smem, s, a, (const float*)S);
     return hipGetLastError();
 }
 // n_key_chunks: 256-key chunks covering the longest context this launch (graph) will see
@@ -1345,7 +1357,7 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
 }
 
 hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(kBlock), 0, s, a);
+    LMRS_LAUNCH_GRID(argmax_final_kernel, dim3(1), kBlock, 0, s, a);
     return hipGetLastError();
 }
 

@@ -4,7 +4,9 @@ Collected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: separate --pmc p
 --kernel-trace only.  Units: the counters are in KiB.  gfx950 correction: FETCH_SIZE reports exactly half of the bytes of a wide
 coalesced streaming read (16 B/lane), which is what these kernels do, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is taken as is.
 
-usage: python tools/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/r1_traffic.json
+The summary records which model / quantisation / build of the kernels it was taken on (bench.py reports `traffic` only on a match).
+
+usage: python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> profiles/<tag>_traffic.json [model] [qtype]
 """
 import collections
 import csv
@@ -21,7 +23,10 @@ def agg(path, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in d.items()}
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, model="llama-3.2-1b", qtype="q8_0"):
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
     f, w = agg(fetch_csv, "FETCH_SIZE"), agg(write_csv, "WRITE_SIZE")
     res = {}
     for k, (fv, n) in f.items():
@@ -30,7 +35,7 @@ def main(fetch_csv, write_csv, out):
                   "hbm_bytes_per_launch": round((2 * fv + wv) * 1024)}
     gemv = {k: v for k, v in res.items() if "gemv" in k}
     # one decode step of Llama-3.2-1B launches, per layer, one of each of the four layer GEMVs, and one classifier GEMV
-    doc = {"note": __doc__.split("usage")[0].strip(), "kernels": res,
+    doc = {"note": __doc__.split("usage")[0].strip(), "model": model, "qtype": qtype, "kernel_source_hash": kernel_source_hash(), "kernels": res,
            "gemv_bytes_weighted_by_launch_count": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemv.values()) / max(1, sum(v["launches"] for v in gemv.values())))}
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
@@ -38,4 +43,4 @@ def main(fetch_csv, write_csv, out):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])

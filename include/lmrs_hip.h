@@ -202,6 +202,34 @@ int lmrs_processor_forward(lmrs_processor* p, const float* out_patches, uint32_t
 int lmrs_processor_hd_transform(const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t w_crop, uint32_t h_crop,
                                 const float* glb_gn, const float* sub_gn, float* out, uint32_t* n_embeds);
 
+/* --------------------------------------------------------------------------------------------------------------------------
+ * The callers either side of the device path, HOST code with the reference's exact results (no GPU needed):
+ *
+ * lmrs_tokenizer_create   <- Tokenizer::new(path)   src/tokenizer.rs:24-64   (data = the bytes of tokenizer.bin)
+ * lmrs_tokenizer_encode   <- Tokenizer::encode(text, bos, eos, chat_format, model_type) -> Vec<u32>   :66-151
+ *     one id per character (or its UTF-8 bytes + 3), then greedy merging of the best-scoring adjacent pair; chat_format wraps the
+ *     ids in the model family's hard-coded template ids.  model_type: 0 GEMMA, 1 LLAMA, 2 PHI.  *n = ids produced (<= cap).
+ * lmrs_tokenizer_decode   <- Tokenizer::decode(token) -> String   :153-163   (bytes, not NUL-terminated; "<0xHH>" -> U+00HH)
+ * lmrs_tokenizer_info     <- the pub fields bos / eos (:15-16) and vocab_size
+ *
+ * lmrs_sampler_create     <- Sampler::new(vocab_size, temperature, top_p, seed)   src/sampler.rs:19-27
+ * lmrs_sampler_sample     <- Sampler::sample(&mut logits) -> u32   :109-129: temperature 0 -> sample_argmax (:29-41); otherwise the
+ *     logits are divided by the temperature and softmax-ed IN PLACE (functional.rs:122-140, one sequential sum - which is why this
+ *     stays on the host: see lmrs_text.cpp) and sample_mult (:43-55) or sample_topp (:67-106) draws with random_f32(seed)
+ *     (functional.rs:34-44).  The reference never advances the seed (:119) - every call of one Sampler uses the same random
+ *     number - and sorts its whole candidate vector, stale entries included (:81): both reproduced. */
+typedef struct lmrs_tokenizer lmrs_tokenizer;
+int lmrs_tokenizer_create(const uint8_t* data, size_t len, lmrs_tokenizer** out);
+void lmrs_tokenizer_destroy(lmrs_tokenizer* t);
+int lmrs_tokenizer_info(const lmrs_tokenizer* t, uint32_t* vocab_size, uint32_t* bos, uint32_t* eos);
+int lmrs_tokenizer_encode(lmrs_tokenizer* t, const char* text, size_t text_len, int bos, int eos, int chat_format, int model_type,
+                          uint32_t* out, size_t cap, size_t* n);
+int lmrs_tokenizer_decode(const lmrs_tokenizer* t, uint32_t token, char* out, size_t cap, size_t* n);
+typedef struct lmrs_sampler lmrs_sampler;
+int lmrs_sampler_create(uint32_t vocab_size, float temperature, float top_p, uint64_t seed, lmrs_sampler** out);
+void lmrs_sampler_destroy(lmrs_sampler* s);
+int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,8 @@ EXPORTS = [
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform",
+    "lmrs_tokenizer_create", "lmrs_tokenizer_destroy", "lmrs_tokenizer_info", "lmrs_tokenizer_encode", "lmrs_tokenizer_decode",
+    "lmrs_sampler_create", "lmrs_sampler_destroy", "lmrs_sampler_sample",
 ]
 
 
@@ -96,6 +98,14 @@ def lib():
         L.lmrs_processor_destroy.restype = None
         L.lmrs_processor_forward.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, C.POINTER(u32)]
         L.lmrs_processor_hd_transform.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, C.POINTER(u32)]
+        L.lmrs_tokenizer_create.argtypes = [vp, sz, C.POINTER(vp)]
+        L.lmrs_tokenizer_destroy.argtypes = [vp]; L.lmrs_tokenizer_destroy.restype = None
+        L.lmrs_tokenizer_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+        L.lmrs_tokenizer_encode.argtypes = [vp, C.c_char_p, sz, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, C.POINTER(sz)]
+        L.lmrs_tokenizer_decode.argtypes = [vp, u32, C.c_char_p, sz, C.POINTER(sz)]
+        L.lmrs_sampler_create.argtypes = [u32, C.c_float, C.c_float, C.c_uint64, C.POINTER(vp)]
+        L.lmrs_sampler_destroy.argtypes = [vp]; L.lmrs_sampler_destroy.restype = None
+        L.lmrs_sampler_sample.argtypes = [vp, vp, C.POINTER(u32)]
         L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
         L.lmrs_bench_step.argtypes = [vp, u32, C.c_int, vp, vp, vp]
         L.lmrs_op_classifier_argmax.argtypes = [C.c_int, vp, vp, vp, vp, sz, sz, C.c_float, C.POINTER(u32), vp]
@@ -374,3 +384,56 @@ class PHI3VProcessor:
             self.close()
         except Exception:
             pass
+
+
+class Tokenizer:
+    """lmrs::tokenizer::Tokenizer (reference src/tokenizer.rs): Tokenizer(path or bytes), .bos / .eos, encode(), decode().  Host code."""
+
+    def __init__(self, src):
+        data = open(src, "rb").read() if isinstance(src, str) else bytes(src)
+        buf = np.frombuffer(data, np.uint8)
+        h = C.c_void_p()
+        _chk(lib().lmrs_tokenizer_create(_p(buf), buf.size, C.byref(h)))
+        self._h = h
+        v, b, e = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _chk(lib().lmrs_tokenizer_info(h, C.byref(v), C.byref(b), C.byref(e)))
+        self.vocab_size, self.bos, self.eos = v.value, b.value, e.value
+
+    def encode(self, text: str, bos: bool, eos: bool, chat_format: bool, model_type: int) -> np.ndarray:
+        raw = text.encode("utf-8")
+        out = np.empty(len(raw) + 32, np.uint32); n = C.c_size_t()
+        _chk(lib().lmrs_tokenizer_encode(self._h, raw, len(raw), int(bos), int(eos), int(chat_format), int(model_type), _p(out), out.size, C.byref(n)))
+        return out[: n.value].copy()
+
+    def decode(self, token: int) -> str:
+        buf = C.create_string_buffer(256); n = C.c_size_t()
+        _chk(lib().lmrs_tokenizer_decode(self._h, token, buf, 256, C.byref(n)))
+        return buf.raw[: n.value].decode("utf-8")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lmrs_tokenizer_destroy(self._h); self._h = None
+
+    __del__ = close
+
+
+class Sampler:
+    """lmrs::sampler::Sampler (reference src/sampler.rs): Sampler(vocab_size, temperature, top_p, seed).sample(logits).  Host code;
+    `logits` (float32, C-contiguous) is modified in place when temperature != 0, as in the reference."""
+
+    def __init__(self, vocab_size: int, temperature: float, top_p: float, seed: int):
+        h = C.c_void_p()
+        _chk(lib().lmrs_sampler_create(vocab_size, temperature, top_p, seed, C.byref(h)))
+        self._h, self.vocab_size = h, vocab_size
+
+    def sample(self, logits: np.ndarray) -> int:
+        assert logits.dtype == np.float32 and logits.flags.c_contiguous and logits.size >= self.vocab_size
+        nxt = C.c_uint32()
+        _chk(lib().lmrs_sampler_sample(self._h, _p(logits), C.byref(nxt)))
+        return nxt.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lmrs_sampler_destroy(self._h); self._h = None
+
+    __del__ = close

@@ -41,6 +41,7 @@ static int fail(const std::string& m) { g_err = m; return -1; }
     } while (0)
 
 extern "C" const char* lmrs_last_error(void) { return g_err.c_str(); }
+namespace lmrs { int text_fail(const char* msg) { return fail(msg); } }       // lmrs_text.cpp reports through the same message slot
 
 namespace {
 

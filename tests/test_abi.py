@@ -95,7 +95,7 @@ def test_cpp_host_mirror_compiles_and_links_against_the_abi(tmp_path):
     exe = tmp_path / "use"
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", ROOT, str(src), "-L", lib_dir, "-llmrs_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)],
                    check=True, capture_output=True)
-    for example in ("chat_greedy.cpp", "image_prefill.cpp"):
+    for example in ("chat_greedy.cpp", "image_prefill.cpp", "chat.cpp"):
         subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", os.path.join(ROOT, "lm.rs_amd", "hostcpp", example)], check=True, capture_output=True)
 
 

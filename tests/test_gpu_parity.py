@@ -631,3 +631,58 @@ def test_image_projector_rejects_bad_geometry(L):
         dev.forward(np.zeros((2, 576, 1024), np.float32), 576 * 1024, 12, 2, 1)      # 3 crops promised, 2 given
     with pytest.raises(L.LmrsError):
         L.PHI3VProcessor(sec[: sec.size // 2])
+
+
+# ------------------------------------------------------------------ the chat-compatible harness, text in / text out
+def _chat_fixture(tmp_path):
+    import struct
+    cfg = S.ModelCfg("llama-2layer", 2048, 8192, 2, 32, 64, 8, 128256, 131072, 1e-5, 500000.0, S.LLAMA)
+    img = S.build_image(cfg, S.Q8_0, seed=91)
+    img.tofile(tmp_path / "model.lmrs")
+    # a tokenizer.bin in the layout tokenizer.rs:24-64 reads, full Llama vocabulary size (the chat template ids must exist)
+    toks = [("<unk>", 0.0), ("<s>", 0.0), ("</s>", 0.0)] + [("<0x%02X>" % b, 0.0) for b in range(256)]
+    toks += [(ch, -1.0 - i) for i, ch in enumerate(" abcdefghijklmnopqrstuvwxyzSO0123456789")]
+    toks += [(m, 5.0 - 0.1 * i) for i, m in enumerate(["he", "ll", "hell", "hello", " w", "or", "ld", " world", "wor", "Se", "ep", "Sep", "20", "24", "2024", "23"])]
+    toks += [("<fill_%d>" % i, 0.0) for i in range(cfg.vocab_size - len(toks))]
+    blob = struct.pack("IIII", len(toks), 16, 128000, 128009)
+    for s_, sc in toks:
+        b = s_.encode(); blob += struct.pack("fI", sc, len(b)) + b
+    (tmp_path / "tokenizer.bin").write_bytes(blob)
+    return cfg, img, blob
+
+
+@pytest.mark.parametrize("temperature", [0.0, 0.7])
+def test_chat_program_text_in_text_out(L, tmp_path, temperature):
+    """hostcpp/chat.cpp - the reference's chat loop (src/bin/chat.rs:148-227) over the C++ mirrors of Tokenizer, Transformer and
+    Sampler - built and RUN on the GPU with a text prompt: what it prints is what the CPU path (the oracle's forward, the second
+    transcription of tokenizer and sampler) produces for the same model, tokenizer, date, temperature, top-p and seed."""
+    import subprocess
+    import text_ref as R
+    cfg, img, blob = _chat_fixture(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "chat")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(root, "lm.rs_amd", "hostcpp", "chat.cpp"), "-I", os.path.join(root, "include"),
+                    "-L", os.path.join(root, "lm.rs_amd"), "-llmrs_hip", f"-Wl,-rpath,{os.path.join(root, 'lm.rs_amd')}", "-o", exe], check=True)
+    n_new, seed, top_p = 6, 4242, 0.9
+    out = subprocess.run([exe, "--model", str(tmp_path / "model.lmrs"), "--tokenizer", str(tmp_path / "tokenizer.bin"), "--temperature", str(temperature),
+                          "--top-p", str(top_p), "--seed", str(seed), "--date", "23 Sep 2024", "--max-tokens", str(n_new)],
+                         input="  hello world  \n", capture_output=True, text=True, check=True).stdout
+    assert out.startswith("You: Assistant:\n"), out
+    printed = out[len("You: Assistant:\n"):]
+    # the CPU path: second transcription of the tokenizer, the oracle's forward, second transcription of the sampler
+    tk = R.Tokenizer(blob)
+    prompt = [128000, 128006, 9125, 128007, 271, 38766, 1303, 33025, 2696, 25, 6790, 220, 2366, 18, 198, 15724, 2696, 25, 220]
+    prompt += tk.encode("23 Sep 2024", False, False, False, 1) + [271, 128009] + tk.encode("hello world", False, False, True, 1)
+    assert (L.Tokenizer(blob).encode("hello world", False, False, True, 1) == np.array(tk.encode("hello world", False, False, True, 1), np.uint32)).all()
+    orc = O.Oracle(img); smp = R.Sampler(cfg.vocab_size, temperature, top_p, seed)
+    pos, nxt, pieces = 0, 0, []
+    for i in range(len(prompt) + n_new - 1):
+        token = prompt[i] if i < len(prompt) else nxt
+        lg = orc.forward(int(token), pos); pos += 1
+        if temperature == 0.0:
+            nxt = int(O.lib().lmrs_ref_argmax(lg.ctypes.data, lg.size))
+        else:                                                   # every call sorts the candidate vector (stale entries stay): run them all, as chat.rs does
+            nxt = smp.sample([np.float32(v) for v in lg])
+        if i >= len(prompt) - 1 and nxt != tk.eos:
+            pieces.append(tk.decode(nxt))
+    assert printed == "".join(pieces) + "\n", (printed, pieces)

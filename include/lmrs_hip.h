@@ -65,6 +65,13 @@ int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, i
 /* Writes the 128-byte ncclUniqueId for lmrs_create_sharded (call on rank 0).  No reference counterpart. */
 int lmrs_comm_unique_id(void* out128);
 
+/* Peer-to-peer transport (no reference counterpart): lmrs_create_sharded with world > 1 and nccl_unique_id == NULL makes a shard whose
+ * exchanges are direct pushes into its peers' exchange arenas over xGMI (a store + flag kernel per exchange) instead of RCCL
+ * all-gathers.  Every rank exports the 64-byte IPC handle of its arena, the launcher distributes all `world` handles in rank order
+ * (any host transport), every rank connects; then the context is used like any other. */
+int lmrs_p2p_handle(lmrs_ctx* ctx, void* out64);
+int lmrs_p2p_connect(lmrs_ctx* ctx, const void* handles);
+
 /* Host-only: the row ranges shard `rank` of `world` owns.  plan[0..9] = q-head first,count; kv-head first,count;
  * wo/w2 row first,count; gate/up pair first,count; classifier row first,count.  wo and w2 are replicated by default
  * (every shard: first 0, count dim - no gather after them); LMRS_SHARD_SPLIT_OUT=1 row-splits them as well. */

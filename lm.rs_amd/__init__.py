@@ -28,7 +28,7 @@ EXPORTS = [
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
     "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
-    "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph",
+    "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform",
     "lmrs_tokenizer_create", "lmrs_tokenizer_destroy", "lmrs_tokenizer_info", "lmrs_tokenizer_encode", "lmrs_tokenizer_decode",
@@ -107,6 +107,8 @@ def lib():
         L.lmrs_sampler_destroy.argtypes = [vp]; L.lmrs_sampler_destroy.restype = None
         L.lmrs_sampler_sample.argtypes = [vp, vp, C.POINTER(u32)]
         L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
+        L.lmrs_p2p_handle.argtypes = [vp, vp]
+        L.lmrs_p2p_connect.argtypes = [vp, vp]
         L.lmrs_bench_step.argtypes = [vp, u32, C.c_int, vp, vp, vp]
         L.lmrs_op_classifier_argmax.argtypes = [C.c_int, vp, vp, vp, vp, sz, sz, C.c_float, C.POINTER(u32), vp]
         _lib = L
@@ -189,6 +191,17 @@ class Transformer:
         out = np.empty(self.args.n_kv_heads * self.args.head_size, np.float32)
         _chk(lib().lmrs_debug_kv(self._h, which, layer, pos, _p(out)))
         return out
+
+    def p2p_handle(self) -> bytes:
+        """Peer-to-peer sharded context: the 64-byte IPC handle of this rank's exchange arena (send it to every peer)."""
+        buf = C.create_string_buffer(64)
+        _chk(lib().lmrs_p2p_handle(self._h, buf))
+        return buf.raw
+
+    def p2p_connect(self, handles) -> None:
+        """handles: the `world` handles in rank order."""
+        blob = b"".join(handles)
+        _chk(lib().lmrs_p2p_connect(self._h, C.create_string_buffer(blob, len(blob))))
 
     def shard_uses_graph(self) -> int:
         return lib().lmrs_shard_uses_graph(self._h)

@@ -89,6 +89,12 @@ struct lmrs_ctx {
     ncclComm_t comm = nullptr;                     // RCCL communicator (one process per GPU); null in group mode
     bool eager = false;                            // sharded step could not be captured: enqueue it every call
     float* part = nullptr;                         // [world][values(cls_grid) | indices(cls_grid)] argmax partials
+    // quantised exchange payloads (Q8_0): one block per shard, [slice int8 | slice/128 f32 scales], blk_* bytes apart
+    bool qpay = false; char *gq_att = nullptr, *gq_h = nullptr; size_t blk_att = 0, blk_h = 0;
+    // peer-to-peer transport: every exchange buffer lives in one fine-grained allocation with the same layout on every shard;
+    // a shard pushes its block straight into its peers' copies (xGMI stores) and raises a flag there (exchange_push_kernel)
+    bool p2p = false, p2p_ready = false; char* xarena = nullptr; size_t xarena_bytes = 0; char* peer_base[8] = {};
+    unsigned *xflags = nullptr, *xseq = nullptr; int* xerr = nullptr; int ex_slot = 0; bool xarena_is_ipc[8] = {};
     // ---- fused attention block (qkv -> attention -> wo in one launch, in-launch arrival counters)
     int fused_cls = 0; unsigned* flags = nullptr; int n_flag_words = 0; int* err = nullptr; int* h_err = nullptr;
 
@@ -249,44 +255,69 @@ int enqueue_step(lmrs_ctx* c) {
 
 // ------------------------------------------------------------------------------------------------
 // Row-sharded step (world > 1), cut into segments at the points where every shard needs the others' rows.
-//   segment 4l+0: [x += tmp] qkv(own heads) -> attention(own heads)      then gather att_out   (att/W per shard)
-//   segment 4l+1: wo (all rows, replicated; or own rows)                 [then gather tmp      (dim/W) if row-split]
-//   segment 4l+2: x += tmp ; w1/w3 (own pairs) -> silu*up                 then gather h         (hidden/W)
-//   segment 4l+3: w2 (all rows, replicated; or own rows)                 [then gather tmp      (dim/W) if row-split]
-//   segment 4L  : x += tmp ; classifier (own vocab rows) + argmax partials  then gather partials
+//   segment 4l+0: [pending residual update] qkv(own heads) -> attention(own heads) [-> quantise own att_out slice]   exchange att
+//   segment 4l+1: wo (all rows if replicated, else own rows)                                                          [exchange tmp]
+//   segment 4l+2: [residual update] w1/w3 (own pairs) -> act(gate)*up [-> quantise own h slice]                        exchange h
+//   segment 4l+3: w2 (all rows if replicated, else own rows)                                                          [exchange tmp]
+//   segment 4L  : [residual update] classifier (own vocab rows) + argmax partials                                      exchange partials
 //   segment 4L+1: argmax over all shards' partials, next-token embedding (replicated)
-// Gathers are in place: shard r's slice sits at buf + r * count on every shard.
+// Residual update: Llama / Phi add the projection's output (in the GEMV epilogue when wo / w2 are replicated, else x += tmp after
+// the exchange); Gemma-2 always goes through tmp: x += rmsnorm(tmp, post_att / post_ffn) (transformer.rs:563-568, 643-650).
+// Exchanges are in place: shard r's block sits at buf + r * stride on every shard.  Payloads:
+//   * Q8_0 models: att_out and h travel QUANTISED - the producing shard runs the reference's quantize (quantization.rs:44-67) on
+//     its own slice (whole 128-groups: bit-identical to quantising the gathered vector) and ships int8 + one f32 scale per group,
+//     3.9x fewer bytes than f32, and the consumers (wo, w2) start from the quantised vector (PRO_PREQ, sliced) instead of each of
+//     their workgroups re-quantising it.  Q4_0 models and LMRS_SHARD_F32_PAYLOAD=1: f32 slices.
+//   * tmp slices (fully row-split form) and the argmax partials: f32 / raw.
 // ------------------------------------------------------------------------------------------------
-struct GatherDesc { float* buf; size_t count; };
+struct ExchangeDesc { char* buf; size_t bytes, stride; };     // bytes valid per shard, blocks `stride` bytes apart (in place)
 static bool shard_split_out() { static const bool v = getenv("LMRS_SHARD_SPLIT_OUT") != nullptr; return v; }
 
 int n_segments(const lmrs_ctx* c) { return 4 * (int)c->args.n_layers + 2; }
 
-GatherDesc gather_after(lmrs_ctx* c, int seg) {
+ExchangeDesc exchange_after(lmrs_ctx* c, int seg) {
     const int L4 = 4 * (int)c->args.n_layers;
+    const ExchangeDesc none{nullptr, 0, 0};
+    auto f32s = [](float* p, size_t count) { return ExchangeDesc{reinterpret_cast<char*>(p), count * 4, count * 4}; };
     if (seg < L4) {
         switch (seg & 3) {
-            case 0: return {c->att_out, (size_t)c->att_dim};
-            case 1: return c->rep_out ? GatherDesc{nullptr, 0} : GatherDesc{c->tmp, (size_t)c->dim_l};
-            case 2: return {c->h, (size_t)c->hid_l};
-            default: return c->rep_out ? GatherDesc{nullptr, 0} : GatherDesc{c->tmp, (size_t)c->dim_l};
+            case 0: return c->qpay ? ExchangeDesc{c->gq_att, (size_t)c->att_dim + (size_t)c->att_dim / 32, c->blk_att} : f32s(c->att_out, (size_t)c->att_dim);
+            case 2: return c->qpay ? ExchangeDesc{c->gq_h, (size_t)c->hid_l + (size_t)c->hid_l / 32, c->blk_h} : f32s(c->h, (size_t)c->hid_l);
+            default: return c->rep_out ? none : f32s(c->tmp, (size_t)c->dim_l);
         }
     }
-    if (seg == L4) return {c->part, (size_t)2 * c->cls_grid};
-    return {nullptr, 0};
+    if (seg == L4) return f32s(c->part, (size_t)2 * c->cls_grid);
+    return none;
 }
 
+// layers_only: the per-layer segments without classifier / argmax (fill_kv_cache on a sharded context: the finished residual in x)
 int run_segment(lmrs_ctx* c, int seg) {
     const lmrs_args& a = c->args;
     const int L4 = 4 * (int)a.n_layers;
-    if (a.model_type == LMRS_GEMMA) return fail("row sharding of the GEMMA variant is not built");
+    const bool gemma = a.model_type == LMRS_GEMMA;
     GemvArgs g{};
-    g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = 0; g.st = c->st;
+    g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = gemma; g.st = c->st;
+    // the residual update that the PREVIOUS projection left pending
+    auto pending_update = [&](const float* norm_w) -> int {
+        if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, norm_w, a.dim, a.rms_norm_eps, c->stream));       // x += rmsnorm(tmp, 1 + w)
+        else if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));                      // x += tmp
+        return 0;
+    };
+    // wo / w2: input quantised by its producers (sliced PRO_PREQ) or f32 (PRO_QUANT); output into x (+=) or tmp
+    auto projection = [&](const void* wq, const float* ws, int n, const float* xin, const char* gq, int slice, size_t blk) -> int {
+        g.wq = wq; g.ws = ws; g.n = n; g.o = c->dim_l;
+        const bool to_tmp = gemma || !c->rep_out;
+        g.out = to_tmp ? c->tmp + c->d0 : c->x;
+        int pro = PRO_QUANT;
+        if (c->qpay) { pro = PRO_PREQ; g.xq_in = gq; g.preq_slice = slice; g.preq_block = (int)blk; } else g.xin = xin;
+        HIP_OK(launch_gemv(g, pro, to_tmp ? EPI_STORE : EPI_RESID, c->stream));
+        return 0;
+    };
     if (seg < L4) {
         const int l = seg >> 2; const DevLayer& L = c->layers[l];
         switch (seg & 3) {
             case 0: {
-                if (l > 0 && !c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+                if (l > 0 && pending_update(c->layers[l - 1].rms_post_ffn)) return -1;
                 g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
                 g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
                 g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
@@ -295,28 +326,35 @@ int run_segment(lmrs_ctx* c, int seg) {
                 t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope;
                 t.out = c->att_out + c->a0;
                 t.n_heads = c->att_dim / a.head_size; t.n_kv_heads = c->kv_dim / a.head_size; t.head_size = a.head_size;
-                t.seq_len = a.seq_len; t.layer = l; t.gemma = 0; t.st = c->st;
-                HIP_OK(launch_attention(t, c->stream));
+                t.seq_len = a.seq_len; t.layer = l; t.gemma = gemma; t.st = c->st;
+                if (c->att_split_chunks) HIP_OK(launch_attention_split(t, c->att_S, c->att_split_chunks, c->stream));
+                else HIP_OK(launch_attention(t, c->stream));
+                if (c->qpay) {
+                    char* blk = c->gq_att + (size_t)c->rank * c->blk_att;
+                    HIP_OK(launch_quantize(c->att_out + c->a0, blk, reinterpret_cast<float*>(blk + c->att_dim), c->att_dim, 0, c->stream));
+                }
                 break;
             }
             case 1:
-                g.wq = L.wo; g.ws = L.so; g.n = c->att_full; g.o = c->dim_l; g.xin = c->att_out; g.out = c->rep_out ? c->x : c->tmp + c->d0;
-                HIP_OK(launch_gemv(g, PRO_QUANT, c->rep_out ? EPI_RESID : EPI_STORE, c->stream));   // replicated: x += wo(att) in the epilogue, as on one GPU
+                if (projection(L.wo, L.so, c->att_full, c->att_out, c->gq_att, c->att_dim, c->blk_att)) return -1;
                 break;
             case 2:
-                if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
-                g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * c->hid_l; g.xin = c->x; g.rms_w = L.rms_post_att; g.out = c->h + c->h0;
-                HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_SWIGLU, c->stream));
+                if (pending_update(L.rms_post_att)) return -1;
+                g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * c->hid_l; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h + c->h0;
+                HIP_OK(launch_gemv(g, PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
+                if (c->qpay) {
+                    char* blk = c->gq_h + (size_t)c->rank * c->blk_h;
+                    HIP_OK(launch_quantize(c->h + c->h0, blk, reinterpret_cast<float*>(blk + c->hid_l), c->hid_l, 0, c->stream));
+                }
                 break;
             default:
-                g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = c->dim_l; g.xin = c->h; g.out = c->rep_out ? c->x : c->tmp + c->d0;
-                HIP_OK(launch_gemv(g, PRO_QUANT, c->rep_out ? EPI_RESID : EPI_STORE, c->stream));
+                if (projection(L.w2, L.s2, (int)a.hidden_dim, c->h, c->gq_h, c->hid_l, c->blk_h)) return -1;
                 break;
         }
         return 0;
     }
     if (seg == L4) {
-        if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+        if (pending_update(c->layers[a.n_layers - 1].rms_post_ffn)) return -1;
         GemvArgs k = cls_args(c);
         HIP_OK(launch_gemv(k, PRO_RMS_QUANT, EPI_CLS, c->stream));
         return 0;
@@ -335,20 +373,90 @@ int run_segment(lmrs_ctx* c, int seg) {
         if (r_ != ncclSuccess) return fail(std::string(#expr) + ": " + ncclGetErrorString(r_));          \
     } while (0)
 
-// the whole sharded step on this shard's stream, RCCL all-gathers between the segments
-int enqueue_step_sharded(lmrs_ctx* c) {
-    const int ns = n_segments(c);
+int enqueue_exchange(lmrs_ctx* c, const ExchangeDesc& e);     // P2P push kernel or RCCL all-gather (below)
+
+// the sharded step (or only its layer segments) on this shard's stream, exchanges between the segments
+int enqueue_step_sharded(lmrs_ctx* c, bool layers_only = false) {
+    const int ns = layers_only ? 4 * (int)c->args.n_layers : n_segments(c);
     for (int s = 0; s < ns; ++s) {
         if (run_segment(c, s)) return -1;
-        const GatherDesc gd = gather_after(c, s);
-        if (gd.buf) NCCL_OK(ncclAllGather(gd.buf + (size_t)c->rank * gd.count, gd.buf, gd.count, ncclFloat, c->comm, c->stream));
+        const ExchangeDesc e = exchange_after(c, s);
+        if (e.buf && enqueue_exchange(c, e)) return -1;
     }
+    if (layers_only) {          // the last layer's residual update, so that x holds the finished residual stream; advance the position
+        const lmrs_args& a = c->args;
+        if (a.model_type == LMRS_GEMMA) HIP_OK(launch_addnorm(c->x, c->tmp, c->layers[a.n_layers - 1].rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));
+        else if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
+        hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
+    }
+    return 0;
+}
+
+// ---- peer-to-peer exchange (the alternative to ncclAllGather for these latency-bound, few-KB messages) -------------------
+// One workgroup: copy my block into the same place of every peer's exchange arena (stores that leave over xGMI; in the
+// single-device verification modes the "peers" are other contexts / processes on the same GPU), make them visible system-wide,
+// raise my flag in every peer's flag row with this exchange's sequence number, then wait until every peer's flag in MY row has
+// reached it.  The arena is fine-grained (uncached in L2) memory, so the kernels that follow read what the peers wrote.
+// Flags are monotonic per (exchange slot of the step, source shard): no reset, no ABA; all shards run the same sequence of steps.
+constexpr int kMaxExchangeSlots = 512;
+struct ExchangeArgs {
+    const char* local; char* peer_dst[8]; unsigned* peer_flag[8]; unsigned* my_flags; unsigned* my_seq; int* err;
+    int bytes, rank, world, slot; long long timeout_ticks;
+};
+__global__ __launch_bounds__(256) void exchange_push_kernel(const ExchangeArgs a) {
+    __shared__ unsigned s_seq;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_seq = *a.my_seq + 1u; *a.my_seq = s_seq; }
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int w = 0; w < a.world; ++w) {
+        if (w == a.rank) continue;
+        for (int off = tid * 16; off < a.bytes; off += 256 * 16)
+            __builtin_nontemporal_store(*reinterpret_cast<const i32x4*>(a.local + off), reinterpret_cast<i32x4*>(a.peer_dst[w] + off));
+    }
+    __threadfence_system();
+    __syncthreads();
+    const unsigned seq = s_seq;
+    if (tid < a.world && tid != a.rank) {
+        __hip_atomic_store(a.peer_flag[tid], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        const bool dead = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // an earlier exchange gave up: do not wait again
+        for (; !dead;) {
+            const unsigned v = __hip_atomic_load(a.my_flags + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(v - seq) >= 0) break;
+            if (wall_clock64() - t0 > a.timeout_ticks) { *a.err = a.slot + 1; break; }    // a peer is gone: report (check_err), do not hang
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+}
+
+int enqueue_exchange(lmrs_ctx* c, const ExchangeDesc& e) {
+    if (c->p2p) {
+        if (!c->p2p_ready) return fail("peer-to-peer transport: peers not connected yet (lmrs_p2p_connect)");
+        if (c->ex_slot >= kMaxExchangeSlots) return fail("too many exchanges in one step");
+        ExchangeArgs x{};
+        const size_t off = (size_t)(e.buf - c->xarena) + (size_t)c->rank * e.stride;
+        x.local = c->xarena + off; x.bytes = (int)((e.bytes + 15) & ~(size_t)15); x.rank = c->rank; x.world = c->world; x.slot = c->ex_slot;
+        for (int w = 0; w < c->world; ++w) {
+            x.peer_dst[w] = c->peer_base[w] + off;
+            x.peer_flag[w] = reinterpret_cast<unsigned*>(c->peer_base[w] + ((char*)c->xflags - c->xarena)) + (size_t)c->ex_slot * 8 + c->rank;
+        }
+        x.my_flags = c->xflags + (size_t)c->ex_slot * 8; x.my_seq = c->xseq + c->ex_slot; x.err = c->xerr;
+        { static const long long ms = getenv("LMRS_P2P_TIMEOUT_MS") ? atoll(getenv("LMRS_P2P_TIMEOUT_MS")) : 3000; x.timeout_ticks = ms * 100000ll; }   // 100 MHz wall clock
+        ++c->ex_slot;
+        hipLaunchKernelGGL(exchange_push_kernel, dim3(1), dim3(256), 0, c->stream, x);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    if (!c->comm) return fail("this context is a member of a lock-step shard group: drive it with lmrs_group_forward");
+    NCCL_OK(ncclAllGather(e.buf + (size_t)c->rank * e.stride, e.buf, e.stride, ncclUint8, c->comm, c->stream));
     return 0;
 }
 
 int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out) {
     hipGraph_t graph = nullptr;
-    c->dbg_node = 0;
+    c->dbg_node = 0; c->ex_slot = 0;
     HIP_OK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
     if (full) rc = c->world > 1 || c->comm ? enqueue_step_sharded(c) : enqueue_step(c);
@@ -393,6 +501,11 @@ int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end, int win_base = -1)
 
 // after a host sync: did a bounded in-launch wait give up?
 int check_err(lmrs_ctx* c) {
+    if (c->xerr) {
+        int e = 0;
+        HIP_OK(hipMemcpy(&e, c->xerr, 4, hipMemcpyDeviceToHost));
+        if (e) { (void)hipMemset(c->xerr, 0, 4); return fail("peer-to-peer exchange " + std::to_string(e - 1) + " timed out waiting for a peer (results of this call are invalid)"); }
+    }
     if (!c->err) return 0;
     HIP_OK(hipMemcpy(c->h_err, c->err, 4, hipMemcpyDeviceToHost));
     if (*c->h_err) return fail("in-launch synchronisation timed out at stage " + std::to_string(*c->h_err - 1) + " (results of this call are invalid)");
@@ -428,12 +541,12 @@ extern "C" int lmrs_shard_plan(const lmrs_args* a, int rank, int world, int* pla
 
 // 1 if the sharded step of this context runs as one captured hipGraph (RCCL collectives inside), 0 if it is enqueued
 // call by call, -1 if the context is not an RCCL shard.
-extern "C" int lmrs_shard_uses_graph(const lmrs_ctx* c) { return !c || !c->comm ? -1 : (c->g_step ? 1 : 0); }
+extern "C" int lmrs_shard_uses_graph(const lmrs_ctx* c) { return !c || !(c->comm || c->p2p) ? -1 : (c->g_step ? 1 : 0); }
 
 extern "C" int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid,
                                    lmrs_ctx** out, size_t* bytes_consumed) {
     if (world < 1 || rank < 0 || rank >= world) return fail("bad rank/world");
-    if (world > 1 && !uid) return fail("world > 1 needs the ncclUniqueId made by lmrs_comm_unique_id on rank 0");
+    // world > 1 without a communicator id: peer-to-peer transport, to be connected with lmrs_p2p_handle / lmrs_p2p_connect
     return create_impl(file, len, device, rank, world, uid, false, out, bytes_consumed);
 }
 
@@ -452,6 +565,56 @@ extern "C" int lmrs_group_create(const uint8_t* file, size_t len, int device, in
             for (int k = 0; k < r; ++k) { lmrs_destroy(shards[k]); shards[k] = nullptr; }
             return -1;
         }
+    if (shards[0]->p2p) {                      // LMRS_GROUP_P2P=1: the shards exchange through the push kernel, concurrently on their own streams
+        for (int r = 0; r < world; ++r) {
+            for (int w = 0; w < world; ++w) shards[r]->peer_base[w] = shards[w]->xarena;
+            shards[r]->p2p_ready = true;
+        }
+    }
+    return 0;
+}
+
+// Peer-to-peer transport between PROCESSES (one per GPU): every rank exports the IPC handle of its exchange arena, the launcher
+// distributes the `world` handles (any host transport), every rank connects.  No reference counterpart.
+extern "C" int lmrs_p2p_handle(lmrs_ctx* c, void* out64) {
+    if (!c || !out64) return fail("NULL argument");
+    if (!c->p2p) return fail("not a peer-to-peer sharded context (create it with lmrs_create_sharded, world > 1, no communicator id)");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    HIP_OK(hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    HIP_OK(hipIpcGetMemHandle(&h, c->xarena));
+    memcpy(out64, &h, 64);
+    return 0;
+}
+extern "C" int lmrs_p2p_connect(lmrs_ctx* c, const void* handles /* world x 64 bytes, in rank order */) {
+    if (!c || !handles) return fail("NULL argument");
+    if (!c->p2p) return fail("not a peer-to-peer sharded context");
+    if (c->p2p_ready) return fail("already connected");
+    HIP_OK(hipSetDevice(c->device));
+    for (int w = 0; w < c->world; ++w) {
+        if (w == c->rank) continue;
+        hipIpcMemHandle_t h; memcpy(&h, static_cast<const char*>(handles) + (size_t)w * 64, 64);
+        void* p = nullptr;
+        HIP_OK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        c->peer_base[w] = static_cast<char*>(p); c->xarena_is_ipc[w] = true;
+    }
+    c->p2p_ready = true;
+    {   // handshake: one exchange of a rank-stamped block, so that a transport that does not work fails HERE, with a message
+        float* probe = c->part;
+        const float stamp = 1000.0f + (float)c->rank;
+        HIP_OK(hipMemcpy(probe + (size_t)c->rank * 64, &stamp, 4, hipMemcpyHostToDevice));
+        const ExchangeDesc e{reinterpret_cast<char*>(probe), 256, 256};
+        c->ex_slot = kMaxExchangeSlots - 2;
+        if (enqueue_exchange(c, e)) return -1;
+        c->ex_slot = 0;
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (check_err(c)) return fail("peer-to-peer handshake: no flag from a peer within the timeout (are all ranks running, and can this GPU reach them?)");
+        for (int w = 0; w < c->world; ++w) {
+            float got = 0; HIP_OK(hipMemcpy(&got, probe + (size_t)w * 64, 4, hipMemcpyDeviceToHost));
+            if (got != 1000.0f + (float)w) return fail("peer-to-peer handshake: the block of rank " + std::to_string(w) + " did not arrive");
+        }
+    }
+    if (capture(c, true, &c->g_step)) { c->g_step = nullptr; c->eager = true; (void)hipGetLastError(); g_err.clear(); }
     return 0;
 }
 
@@ -465,23 +628,30 @@ extern "C" int lmrs_group_forward(lmrs_ctx** sh, int world, uint32_t token, uint
     HIP_OK(hipSetDevice(c0->device));
     for (int r = 0; r < world; ++r) {
         lmrs_ctx* c = sh[r];
-        if (c->world != world || c->rank != r || c->comm) return fail("contexts are not a shard group made by lmrs_group_create");
+        if (c->world != world || c->rank != r || c->comm || (c->p2p && !c->p2p_ready)) return fail("contexts are not a shard group made by lmrs_group_create");
         c->h_tok[0] = token;
         HIP_OK(hipMemcpyAsync(c->tokens + pos, c->h_tok, 4, hipMemcpyHostToDevice, c->stream));
         if (set_state(c, pos, 0)) return -1;
         HIP_OK(launch_embed(embed_args(c), c->stream));
     }
     const int ns = n_segments(c0);
+    if (c0->p2p) {
+        // every shard's whole step on its own stream, all in flight at once: the exchanges are the push kernels, the shards really
+        // wait for each other on the device (as W processes on W GPUs would)
+        for (int r = 0; r < world; ++r) { sh[r]->ex_slot = 0; if (enqueue_step_sharded(sh[r])) return -1; }
+        HIP_OK(hipDeviceSynchronize());
+        for (int r = 0; r < world; ++r) if (check_err(sh[r])) return -1;
+    } else
     for (int s = 0; s < ns; ++s) {
         for (int r = 0; r < world; ++r) if (run_segment(sh[r], s)) return -1;
         HIP_OK(hipDeviceSynchronize());
-        const GatherDesc g0 = gather_after(c0, s);
+        const ExchangeDesc g0 = exchange_after(c0, s);
         if (!g0.buf) continue;
         for (int dst = 0; dst < world; ++dst)
             for (int src = 0; src < world; ++src) {
                 if (src == dst) continue;
-                const GatherDesc gs = gather_after(sh[src], s), gd = gather_after(sh[dst], s);
-                HIP_OK(hipMemcpyAsync(gd.buf + (size_t)src * gd.count, gs.buf + (size_t)src * gs.count, gs.count * 4, hipMemcpyDeviceToDevice, sh[dst]->stream));
+                const ExchangeDesc gs = exchange_after(sh[src], s), gd = exchange_after(sh[dst], s);
+                HIP_OK(hipMemcpyAsync(gd.buf + (size_t)src * gd.stride, gs.buf + (size_t)src * gs.stride, gs.bytes, hipMemcpyDeviceToDevice, sh[dst]->stream));
             }
         HIP_OK(hipDeviceSynchronize());
     }
@@ -536,12 +706,15 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     c->a0 = (int)a0; c->d0 = (int)d0; c->h0 = (int)h0; c->v0 = (int)v0;
     c->rep_out = rep_out;
     const bool sharded = world > 1 || uid != nullptr;
+    // transport of the exchanges: RCCL when a communicator id is given; otherwise peer-to-peer pushes (separate processes
+    // connect through lmrs_p2p_handles / lmrs_p2p_connect; a lock-step group on one device uses plain copies unless LMRS_GROUP_P2P=1)
+    c->p2p = sharded && world > 1 && !uid && (!group_mode || getenv("LMRS_GROUP_P2P"));
     auto cleanup = [&]() { lmrs_destroy(c); return -1; };
 #define CK(call) do { if ((call)) return cleanup(); } while (0)
 #define HCK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return cleanup(); } } while (0)
     HCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HCK(hipEventCreate(&c->ev0)); HCK(hipEventCreate(&c->ev1));
-    if (sharded && !group_mode) {
+    if (sharded && !group_mode && uid) {
         ncclUniqueId id; memcpy(&id, uid, sizeof id);
         ncclResult_t nr = ncclCommInitRank(&c->comm, world, id, rank);
         if (nr != ncclSuccess) { fail(std::string("ncclCommInitRank: ") + ncclGetErrorString(nr)); return cleanup(); }
@@ -568,6 +741,10 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     need((size_t)a.seq_len * a.head_size * 4);                               // rope table
     need(dim * 4); need(att_l * 4); need(kv_l * 4); need(att * 4); need(hid * 4); need(V * 4); need(dim * 4); need(dim * 4);
     need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4); need(W * 2 * kMaxArgmaxParts * 4);
+    // quantised exchange payloads (Q8_0, whole 128-groups per shard): one padded block per shard
+    c->qpay = sharded && !c->q4 && att_l % 128 == 0 && hid_l % 128 == 0 && !getenv("LMRS_SHARD_F32_PAYLOAD");
+    c->blk_att = pad256(att_l + att_l / 32); c->blk_h = pad256(hid_l + hid_l / 32);
+    need(W * c->blk_att); need(W * c->blk_h);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
     c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8); need(nl * kFusedFlagWordsPerLayer * 4 + 512);
     total += 4096;
@@ -631,10 +808,27 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     // ---- state
     c->k_cache = c->alloc<float>(kvn); c->v_cache = c->alloc<float>(kvn);
     c->rope = c->alloc<float>((size_t)a.seq_len * a.head_size);
-    c->x = c->alloc<float>(dim); c->q = c->alloc<float>(att_l); c->k_raw = c->alloc<float>(kv_l); c->att_out = c->alloc<float>(att);
-    c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V); c->tmp = c->alloc<float>(dim); c->x2 = c->alloc<float>(dim);
+    c->x = c->alloc<float>(dim); c->q = c->alloc<float>(att_l); c->k_raw = c->alloc<float>(kv_l); c->x2 = c->alloc<float>(dim);
     c->part_val = c->alloc<float>(kMaxArgmaxParts); c->part_idx = c->alloc<int>(kMaxArgmaxParts);
-    c->part = c->alloc<float>(W * 2 * kMaxArgmaxParts);
+    if (c->p2p) {
+        // every buffer a peer writes into: one fine-grained (L2-uncached, system-coherent) allocation, same layout on every shard
+        size_t xo = 0;
+        auto xneed = [&](size_t b) { const size_t o = xo; xo += pad256(b); return o; };
+        const size_t o_att = xneed(att * 4), o_h = xneed(hid * 4), o_tmp = xneed(dim * 4), o_logits = xneed(V * 4), o_part = xneed(W * 2 * kMaxArgmaxParts * 4),
+                     o_gqa = xneed(W * c->blk_att), o_gqh = xneed(W * c->blk_h), o_flags = xneed((size_t)kMaxExchangeSlots * 8 * 4), o_seq = xneed((size_t)kMaxExchangeSlots * 4), o_err = xneed(256);
+        HCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->xarena), xo, hipDeviceMallocFinegrained));
+        c->xarena_bytes = xo;
+        HCK(hipMemset(c->xarena, 0, xo));
+        c->att_out = reinterpret_cast<float*>(c->xarena + o_att); c->h = reinterpret_cast<float*>(c->xarena + o_h); c->tmp = reinterpret_cast<float*>(c->xarena + o_tmp);
+        c->logits = reinterpret_cast<float*>(c->xarena + o_logits); c->part = reinterpret_cast<float*>(c->xarena + o_part);
+        c->gq_att = c->xarena + o_gqa; c->gq_h = c->xarena + o_gqh;
+        c->xflags = reinterpret_cast<unsigned*>(c->xarena + o_flags); c->xseq = reinterpret_cast<unsigned*>(c->xarena + o_seq); c->xerr = reinterpret_cast<int*>(c->xarena + o_err);
+        c->peer_base[rank] = c->xarena;
+    } else {
+        c->att_out = c->alloc<float>(att); c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V); c->tmp = c->alloc<float>(dim);
+        c->part = c->alloc<float>(W * 2 * kMaxArgmaxParts);
+        c->gq_att = c->alloc<char>(W * c->blk_att); c->gq_h = c->alloc<char>(W * c->blk_h);
+    }
     c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
     if (getenv("LMRS_DEBUG_TIMELINE")) { c->dbg = c->alloc<unsigned long long>(8 * 1024); if (c->dbg) HCK(hipMemsetAsync(c->dbg, 0, 8 * 1024 * 8, c->stream)); }
     // Opt-in (LMRS_FUSED=1): measured on MI355X the in-launch arrive/wait edges cost as much as the two kernel boundaries
@@ -687,10 +881,12 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         CK(capture(c, false, &c->g_layers));
         // from this position on a step uses the split attention (scores by key chunk, V by dim slice): graphs captured on first use
         if (!c->dbg && !c->fused_cls) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
-    } else if (!group_mode) {
+    } else if (c->comm) {
         // RCCL collectives inside a captured graph: use it when the runtime accepts it, else enqueue every step
         if (capture(c, true, &c->g_step)) { c->g_step = nullptr; c->eager = true; (void)hipGetLastError(); g_err.clear(); }
     }
+    // (peer-to-peer contexts capture their step graph in lmrs_p2p_connect, once the peers' arenas are known)
+    if (sharded) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
 #undef CK
 #undef HCK
     *out = c;
@@ -712,6 +908,8 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->h_tok) (void)hipHostFree(c->h_tok);
     if (c->h_st) (void)hipHostFree(c->h_st);
     if (c->h_err) (void)hipHostFree(c->h_err);
+    for (int w = 0; w < 8; ++w) if (c->xarena_is_ipc[w] && c->peer_base[w]) (void)hipIpcCloseMemHandle(c->peer_base[w]);
+    if (c->xarena) (void)hipFree(c->xarena);
     if (c->arena) (void)hipFree(c->arena);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -723,23 +921,36 @@ extern "C" const lmrs_args* lmrs_get_args(const lmrs_ctx* c) { return c ? &c->ar
 
 // one decode step on the context's stream: the captured graph, or (sharded, capture refused) eager launches
 static int launch_step(lmrs_ctx* c, uint32_t pos) {
-    if (c->g_step && c->att_split_pos > 0 && (int)pos >= c->att_split_pos) {
-        // bucket b covers positions below 1024 << b
-        int b = 0;
+    const bool sharded = c->comm || c->p2p;
+    if (c->p2p && !c->p2p_ready) return fail("peer-to-peer transport: peers not connected yet (lmrs_p2p_connect)");
+    if (sharded && c->world > 1 && !c->comm && !c->p2p) return fail("this context is a member of a lock-step shard group: drive it with lmrs_group_forward");
+    const bool want_split = c->att_split_pos > 0 && (int)pos >= c->att_split_pos;
+    int b = 0;                                               // bucket b covers positions below 1024 << b
+    if (want_split) {
         while (b < 3 && pos >= (1024u << b)) ++b;
-        if (!c->g_step_long[b]) {
-            if (!c->att_S) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->att_S), attention_split_scratch_floats((int)c->args.n_heads, (int)c->args.seq_len) * 4));
-            c->att_split_chunks = 4 << b;
-            const int rc = capture(c, true, &c->g_step_long[b]);
-            c->att_split_chunks = 0;
-            if (rc) return -1;
+        if (!c->att_S) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->att_S), attention_split_scratch_floats(c->att_dim / (int)c->args.head_size, (int)c->args.seq_len) * 4));
+    }
+    if (c->g_step) {
+        if (want_split) {
+            if (!c->g_step_long[b]) {
+                c->att_split_chunks = 4 << b;
+                const int rc = capture(c, true, &c->g_step_long[b]);
+                c->att_split_chunks = 0;
+                if (rc) return -1;
+            }
+            HIP_OK(hipGraphLaunch(c->g_step_long[b], c->stream));
+            return 0;
         }
-        HIP_OK(hipGraphLaunch(c->g_step_long[b], c->stream));
+        HIP_OK(hipGraphLaunch(c->g_step, c->stream));
         return 0;
     }
-    if (c->g_step) { HIP_OK(hipGraphLaunch(c->g_step, c->stream)); return 0; }
-    if (c->comm && c->eager) return enqueue_step_sharded(c);
-    return fail("this context is a member of a shard group: drive it with lmrs_group_forward");
+    if (sharded && c->eager) {                               // the runtime refused to capture the collectives: enqueue every step
+        c->att_split_chunks = want_split ? 4 << b : 0; c->ex_slot = 0;
+        const int rc = enqueue_step_sharded(c);
+        c->att_split_chunks = 0;
+        return rc;
+    }
+    return fail("this context is a member of a lock-step shard group: drive it with lmrs_group_forward");
 }
 
 static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
@@ -756,7 +967,13 @@ static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
 
 extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** logits) {
     if (step_once(c, token, pos)) return -1;
-    if (c->world > 1) NCCL_OK(ncclAllGather(c->logits + c->v0, c->logits, (size_t)c->voc_l, ncclFloat, c->comm, c->stream));
+    if (c->world > 1) {                                        // every shard returns the whole logits vector
+        const ExchangeDesc e{reinterpret_cast<char*>(c->logits), (size_t)c->voc_l * 4, (size_t)c->voc_l * 4};
+        const int keep = c->ex_slot; c->ex_slot = kMaxExchangeSlots - 1;      // a slot of its own: the step graph's slots were fixed at capture
+        const int rc = enqueue_exchange(c, e);
+        c->ex_slot = keep;
+        if (rc) return -1;
+    }
     HIP_OK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->args.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
@@ -884,8 +1101,33 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
 extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, uint32_t curr_pos, uint32_t* new_pos) {
     if (!c || !embeddings) return fail("NULL argument");
     if ((size_t)curr_pos + n > c->args.seq_len) return fail("positions out of range");
-    if (!c->g_layers) return fail("fill_kv_cache is not built for row-sharded contexts");
     HIP_OK(hipSetDevice(c->device));
+    if (!c->g_layers) {
+        // Row-sharded context: forward_layer(sl = n) is, value for value, n single-token passes through the layers; each token goes
+        // through the sharded layer segments (exchanges included), every shard ends with the whole residual stream in x.
+        if (!(c->comm || (c->p2p && c->p2p_ready))) return fail("fill_kv_cache: this sharded context has no transport (lock-step groups are driven by lmrs_group_forward)");
+        const size_t dim = c->args.dim;
+        if (set_state(c, curr_pos, 0, (int)curr_pos)) return -1;
+        const int chunks0 = c->att_split_chunks;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t pos = curr_pos + i;
+            int b = 0;
+            if (c->att_split_pos > 0 && (int)pos >= c->att_split_pos) {
+                while (b < 3 && pos >= (1024u << b)) ++b;
+                if (!c->att_S) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->att_S), attention_split_scratch_floats(c->att_dim / (int)c->args.head_size, (int)c->args.seq_len) * 4));
+                c->att_split_chunks = 4 << b;
+            } else c->att_split_chunks = 0;
+            HIP_OK(hipMemcpyAsync(c->x, embeddings + (size_t)i * dim, dim * 4, hipMemcpyHostToDevice, c->stream));
+            c->ex_slot = 0;
+            if (enqueue_step_sharded(c, true)) { c->att_split_chunks = chunks0; return -1; }
+            HIP_OK(hipMemcpyAsync(embeddings + (size_t)i * dim, c->x, dim * 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        c->att_split_chunks = chunks0;
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (check_err(c)) return -1;
+        if (new_pos) *new_pos = curr_pos + n;
+        return 0;
+    }
     if (prefill_batched_ok(c) && n > 1) {
         // forward_layer(sl = n): GEMMs over the token batch on the int8 matrix cores, kPrefillTokens tokens at a time
         // (a later chunk only needs the K/V rows of the earlier ones, exactly as inside the reference's single call).

@@ -29,6 +29,7 @@ struct GemvArgs {
     // activation input
     const float* xin;        // PRO_QUANT / PRO_RMS_QUANT: n f32
     const void* xq_in; const float* xs_in;   // PRO_PREQ: already quantised activation
+    int preq_slice, preq_block;              // PRO_PREQ, sliced form (0: contiguous): blocks of [preq_slice int8 | preq_slice/128 scales], preq_block bytes apart
     const float* rms_w; float eps; int add_unit;   // PRO_RMS_QUANT
     const float* delta; const float* add_w; float* xout;   // PRO_ADD_RMS_QUANT: x' = xin + rmsnorm(delta, add_w) -> xout (a buffer other than xin)
     // outputs

@@ -228,6 +228,21 @@ __device__ __forceinline__ int group_partial_dot(const i32x4& w, const int8_t* x
     return d;
 }
 
+// PRO_PREQ input.  Contiguous (preq_slice == 0): xq_in = n int8 (n/2 packed bytes for Q4_0), xs_in = n/128 scales.  Sliced
+// (row-sharded step, Q8_0): the activation was quantised by the shards that produced it and gathered as one block per shard,
+// [preq_slice int8 | preq_slice / 128 f32 scales] every preq_block bytes; element e lives in block e / preq_slice.
+__device__ __forceinline__ const int8_t* preq_bytes(const GemvArgs& a, int e) {
+    const int8_t* base = reinterpret_cast<const int8_t*>(a.xq_in);
+    if (a.preq_slice == 0) return base + e;
+    const int r = e / a.preq_slice;
+    return base + (size_t)r * a.preq_block + (e - r * a.preq_slice);
+}
+__device__ __forceinline__ float preq_scale(const GemvArgs& a, int g) {
+    if (a.preq_slice == 0) return a.xs_in[g];
+    const int e = g * 128, r = e / a.preq_slice;
+    return *reinterpret_cast<const float*>(reinterpret_cast<const int8_t*>(a.xq_in) + (size_t)r * a.preq_block + a.preq_slice + ((e - r * a.preq_slice) >> 7) * 4);
+}
+
 // sample_argmax (sampler.rs:29-41) starts from probabilities[0] and only moves on a strict `>`: a NaN logit at index 0 is
 // never displaced.  The workgroup that owns global row 0 (block 0 of the launch whose row_offset is 0) reports that case by
 // storing index -1 in its partial; argmax_final_kernel - on every shard, the partials are gathered - then answers 0.
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     if constexpr (PRO == PRO_PREQ) {
         if constexpr (!Q4) {
             for (int e = threadIdx.x * 16; e < n; e += kBlock * 16)
-                *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
+                *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(preq_bytes(a, e));
         } else {
             const uint8_t* src = reinterpret_cast<const uint8_t*>(a.xq_in);
             for (int b = threadIdx.x * 4; b < n / 2; b += kBlock * 4) {   // 4 packed bytes = one octet of elements
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 *reinterpret_cast<int*>(xq + 2 * b + 4) = nib_signed(pk >> 4);
             }
         }
-        for (int g = threadIdx.x; g < G; g += kBlock) xs[g] = a.xs_in[g];
+        for (int g = threadIdx.x; g < G; g += kBlock) xs[g] = preq_scale(a, g);
     } else {
         if constexpr (PRO == PRO_RMS_QUANT) rmsnorm_inplace(v, nw, n, a.eps, a.add_unit, scratch);
         quantize_to_lds<Q4, NP>(v, n, xq, xs, nullptr, nullptr);
@@ -502,8 +517,8 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     if constexpr (PRO == PRO_PREQ) {
         constexpr int XB = Q4 ? N / 2 : N;
         for (int e = threadIdx.x * 16; e < XB; e += NTH * 16)
-            *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(reinterpret_cast<const int8_t*>(a.xq_in) + e);
-        for (int g = threadIdx.x; g < V::G; g += NTH) xs[g] = a.xs_in[g];
+            *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(preq_bytes(a, e));
+        for (int g = threadIdx.x; g < V::G; g += NTH) xs[g] = preq_scale(a, g);
     } else {
         unsigned long long* dbg = blockIdx.x == 0 ? a.dbg : nullptr;
         if constexpr (PRO == PRO_ADD_RMS_QUANT) {
@@ -599,6 +614,8 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     X(2048, 32, PRO_RMS_QUANT, EPI_QKV, 256, false) X(2048, 32, PRO_QUANT, EPI_RESID, 256, false) X(2048, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256, false) \
     X(2048, 8, PRO_RMS_QUANT, EPI_CLS, 256, false) X(2048, 32, PRO_PREQ, EPI_STORE, 256, false) X(2048, 8, PRO_PREQ, EPI_STORE, 256, false) \
     X(8192, 64, PRO_QUANT, EPI_RESID, 512, false) X(8192, 32, PRO_PREQ, EPI_STORE, 256, false) \
+    /* row-sharded step: the activation arrives quantised from the shards that produced it */                         \
+    X(2048, 32, PRO_PREQ, EPI_RESID, 256, false) X(8192, 32, PRO_PREQ, EPI_RESID, 256, false) X(3072, 32, PRO_PREQ, EPI_RESID, 256, false) \
     /* Q8_0, dim 3072: Llama-3.2-3B, Phi-3.5 */                                                                         \
     X(3072, 32, PRO_RMS_QUANT, EPI_QKV, 256, false) X(3072, 16, PRO_RMS_QUANT, EPI_QKV, 256, false) X(3072, 32, PRO_QUANT, EPI_RESID, 256, false) \
     X(3072, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256, false) X(3072, 16, PRO_RMS_QUANT, EPI_CLS, 256, false)                  \
@@ -712,11 +729,11 @@ static GemvShape pick_shape(const GemvArgs& a, int epi) {
 // (prologue, epilogue) that handles any n (one cluster per row, NP = 10).
 #define LMRS_GEMV_TABLE(X)                                                                                 \
     /* generic */                                                                                          \
-    X(8, 16, 10, PRO_PREQ, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_RESID, false) \
+    X(8, 16, 10, PRO_PREQ, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_STORE, false) X(8, 16, 10, PRO_QUANT, EPI_RESID, false) X(8, 16, 10, PRO_PREQ, EPI_RESID, false) \
     X(8, 16, 10, PRO_RMS_QUANT, EPI_STORE, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_QKV, false)              \
     X(8, 16, 10, PRO_RMS_QUANT, EPI_SWIGLU, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_GELU, false) X(8, 16, 10, PRO_RMS_QUANT, EPI_CLS, false) \
     /* generic, 10240 < n <= 16384 (hidden_dim 14336 of Gemma-2-9B / Llama-3.1-8B): the inputs that are only quantised */      \
-    X(8, 16, 16, PRO_PREQ, EPI_STORE, false) X(8, 16, 16, PRO_QUANT, EPI_STORE, false) X(8, 16, 16, PRO_QUANT, EPI_RESID, false) \
+    X(8, 16, 16, PRO_PREQ, EPI_STORE, false) X(8, 16, 16, PRO_QUANT, EPI_STORE, false) X(8, 16, 16, PRO_QUANT, EPI_RESID, false) X(8, 16, 16, PRO_PREQ, EPI_RESID, false) \
     X(4, 16, 16, PRO_PREQ, EPI_STORE, true) X(4, 16, 16, PRO_QUANT, EPI_STORE, true) X(4, 16, 16, PRO_QUANT, EPI_RESID, true) \
     /* n = 2048 (Llama-3.2-1B dim; Gemma-2-2B att_dim) */                                                  \
     X(32, 4, 2, PRO_RMS_QUANT, EPI_QKV, false) X(32, 4, 2, PRO_QUANT, EPI_RESID, false) X(32, 4, 2, PRO_QUANT, EPI_STORE, false) \

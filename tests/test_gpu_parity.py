@@ -436,11 +436,23 @@ def test_split_attention_for_long_contexts(L, monkeypatch, cfg, q, n_steps, spli
 
 
 # ------------------------------------------------------------------ row sharding
-@pytest.mark.parametrize("cfg,world", [("mini-llama", 2), ("mini-llama", 8), ("mini-llama3b", 4), ("mini-phi", 8)])
-def test_row_sharding_is_bit_identical(L, cfg, world):
-    """`world` logical shards on ONE device (same kernels, same partition as the multi-GPU path, copies instead of
-    RCCL): every logit must equal the unsharded CPU path bit for bit."""
-    img = S.build_image(cfg, S.Q8_0, seed=31)
+@pytest.mark.parametrize("cfg,q,world,mode", [
+    ("mini-llama", S.Q8_0, 2, "int8"), ("mini-llama", S.Q8_0, 8, "int8"), ("mini-llama3b", S.Q8_0, 4, "int8"), ("mini-phi", S.Q8_0, 8, "int8"),
+    ("mini-llama", S.Q8_0, 4, "f32"), ("mini-llama", S.Q8_0, 4, "split"), ("mini-llama3b", S.Q8_0, 8, "split"),
+    ("mini-gemma", S.Q8_0, 2, "int8"), ("mini-gemma", S.Q8_0, 4, "split"), ("mini-gemma", S.Q4_0, 4, "int8"), ("mini-llama", S.Q4_0, 4, "int8"),
+    ("mini-llama", S.Q8_0, 2, "p2p"), ("mini-llama3b", S.Q8_0, 2, "p2p"), ("mini-gemma", S.Q8_0, 2, "p2p-split")])
+def test_row_sharding_is_bit_identical(L, monkeypatch, cfg, q, world, mode):
+    """`world` logical shards on ONE device - same kernels, same partition as the multi-GPU path: every logit must equal the unsharded
+    CPU path bit for bit.  int8: att_out / h travel quantised by their producers (Q8_0; Q4_0 models fall back to f32 slices);
+    f32: LMRS_SHARD_F32_PAYLOAD=1; split: wo / w2 row-split as well (four exchanges per layer); Gemma-2: the norm + add steps
+    around the exchanges; p2p: the shards run CONCURRENTLY on their own streams and exchange through the push kernel (stores into
+    the peers' arenas + flags) instead of lock-step copies (two shards only: a process has four hardware queues by default, and
+    with more shards in ONE process two of them share a queue - the second's kernels would sit behind the first's waiting exchange
+    kernel; separate processes, the real launch shape, each have their own: test_peer_to_peer_shards_in_separate_processes)."""
+    if mode == "f32": monkeypatch.setenv("LMRS_SHARD_F32_PAYLOAD", "1")
+    if "split" in mode: monkeypatch.setenv("LMRS_SHARD_SPLIT_OUT", "1")
+    if "p2p" in mode: monkeypatch.setenv("LMRS_GROUP_P2P", "1")
+    img = S.build_image(cfg, q, seed=31)
     grp = L.ShardGroup(img, world)
     orc = O.Oracle(img)
     prompt = S.prompt_tokens(cfg, 4, 31)
@@ -449,10 +461,79 @@ def test_row_sharding_is_bit_identical(L, cfg, world):
         t = int(prompt[pos]) if pos < len(prompt) else tok
         lg, nxt = grp.forward(t, pos)
         lo = orc.forward(t, pos)
-        assert_bit_equal(lg, lo, f"{cfg} world={world} logits at pos {pos}")
+        assert_bit_equal(lg, lo, f"{cfg} world={world} {mode} logits at pos {pos}")
         tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
         assert nxt == tok
     grp.close()
+
+
+def _p2p_rank(rank, world, img_path, cfg, env, q_in, q_out):
+    """One process of the peer-to-peer test: its shard of the model on device 0, handles exchanged through the parent."""
+    try:
+        import os, sys
+        os.environ.update(env)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+        import numpy as np
+        import lmrs_amd
+        from tools import synth_lmrs as S
+        img = np.fromfile(img_path, np.uint8)
+        m = lmrs_amd.Transformer(img, device=0, rank=rank, world=world)          # no communicator id: peer-to-peer transport
+        q_out.put((rank, "handle", m.p2p_handle()))
+        m.p2p_connect(q_in.get(timeout=120))
+        prompt = S.prompt_tokens(cfg, 6, 44)
+        emb = m.get_embeddings(prompt)
+        newp = m.fill_kv_cache(emb, 0)                                           # sharded fill_kv_cache: layer segments token by token
+        toks = m.generate_greedy(S.prompt_tokens(cfg, 3, 45), 20, start_pos=newp)   # crosses LMRS_ATT_SPLIT_POS: split attention on shards
+        lg = m.forward(int(toks[-1]), newp + 3 + 19).copy()
+        q_out.put((rank, "done", (emb, newp, toks, lg, m.shard_uses_graph())))
+        m.close()
+    except Exception:
+        import traceback
+        q_out.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("cfg,world", [("mini-llama", 2), ("mini-gemma", 2), ("mini-llama3b", 4)])
+def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world):
+    """The multi-GPU launch shape on a one-GPU box: `world` PROCESSES, one shard each (here all on device 0), exchange arenas opened
+    through IPC handles, every exchange a push kernel that really waits for the other process's flag.  fill_kv_cache on the shards,
+    greedy decoding across the split-attention switch, full logits on every rank - all bit-equal to the CPU path."""
+    import multiprocessing as mp
+    img = S.build_image(cfg, S.Q8_0, seed=43)
+    path = str(tmp_path / "m.lmrs"); img.tofile(path)
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue(); q_in = [ctx.Queue() for _ in range(world)]
+    env = {"LMRS_ATT_SPLIT_POS": "16", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LMRS_P2P_TIMEOUT_MS": "1500"}
+    procs = [ctx.Process(target=_p2p_rank, args=(r, world, path, cfg, env, q_in[r], q_out)) for r in range(world)]
+    for p in procs: p.start()
+    try:
+        handles = {}
+        while len(handles) < world:
+            r, kind, val = q_out.get(timeout=90)
+            assert kind == "handle", val
+            handles[r] = val
+        for r in range(world): q_in[r].put([handles[i] for i in range(world)])
+        res = {}
+        while len(res) < world:
+            r, kind, val = q_out.get(timeout=90)
+            assert kind == "done", val
+            res[r] = val
+    finally:
+        for p in procs: p.join(30)
+        for p in procs:
+            if p.is_alive(): p.kill()
+    orc = O.Oracle(img)
+    prompt = S.prompt_tokens(cfg, 6, 44)
+    e_ref = orc.get_embeddings(prompt); p_ref = orc.fill_kv_cache(e_ref, 0)
+    t_ref = orc.generate_greedy(S.prompt_tokens(cfg, 3, 45), 20, start_pos=p_ref)
+    l_ref = orc.forward(int(t_ref[-1]), p_ref + 3 + 19)
+    for r in range(world):
+        emb, newp, toks, lg, graph = res[r]
+        assert newp == p_ref
+        assert_bit_equal(emb, e_ref, f"rank {r}: embeddings after the sharded fill_kv_cache")
+        assert (toks == t_ref).all(), (r, toks, t_ref)
+        assert_bit_equal(lg, l_ref, f"rank {r}: logits")
+        print(f"rank {r}: step graph captured = {graph}")
 
 
 def test_rccl_path_with_one_rank(L):

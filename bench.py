@@ -121,8 +121,16 @@ def main():
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
+        # LMRS_BENCH_ONE_DEVICE=1 (verification on a one-GPU box): every rank uses device 0 and the process group runs on gloo
+        # (RCCL refuses two ranks on one device); the shards then exchange through the peer-to-peer transport, as on a real node.
+        one_device = os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1"
+        if one_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     hip = ctypes.CDLL("libamdhip64.so")
 
     def device_sync():
@@ -153,9 +161,35 @@ def main():
     # N > 1: ONE decode stream, weight matrices row-split over the N GPUs (one process per GPU), RCCL all-gathers
     # of the per-shard slices over xGMI between the fused kernels.  Token ids stay identical.
     sharded = dist is not None
+    transport = None
     if sharded:
-        uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
-        model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
+        # Transport of the per-layer exchanges (a few KB each, latency-bound): peer-to-peer pushes over xGMI by default (a store + flag
+        # kernel per exchange, arenas opened through IPC handles; lmrs_p2p_connect ends with a handshake), RCCL all-gathers if any rank
+        # cannot connect (or LMRS_BENCH_TRANSPORT=rccl).  With a world of one (LMRS_BENCH_FORCE_DIST) only the RCCL path exists.
+        want = os.environ.get("LMRS_BENCH_TRANSPORT", "p2p" if world > 1 else "rccl")
+        model = None
+        if want == "p2p":
+            ok = 1
+            try:
+                model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world)
+                handles = [None] * world
+                dist.all_gather_object(handles, model.p2p_handle())
+                model.p2p_connect(handles)
+            except Exception as e:                      # noqa: BLE001 - any failure means: fall back, together
+                print(f"[rank {rank}] peer-to-peer transport unavailable: {e}", file=sys.stderr)
+                ok = 0
+            import torch
+            flag = torch.tensor([ok], device="cpu" if dist.get_backend() == "gloo" else "cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                transport = "p2p"
+            else:
+                if model is not None:
+                    model.close()
+                model = None
+        if model is None:
+            uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
+            model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
+            transport = "rccl"
     else:
         model = lmrs_amd.Transformer(img, device=local_rank)
 
@@ -167,8 +201,16 @@ def main():
     toks, dev_sec = model.generate_greedy(first, K, start_pos=W, timing=True)
     device_sync(); barrier()
     t2 = time.perf_counter()
-    elapsed = max_over_ranks(dist, t2 - t1, "cuda" if dist is not None else None)
+    elapsed = max_over_ranks(dist, t2 - t1, ("cpu" if dist.get_backend() == "gloo" else "cuda") if dist is not None else None)
     gen = np.concatenate([first, toks])[: K + 1]          # token ids produced after positions W-1 .. W+K-1
+    shard_steps = None
+    if sharded:
+        # per-kernel / per-exchange durations inside the sharded step (every rank takes part: the exchanges wait for the peers)
+        try:
+            shard_steps = model.bench_step(W + K, 8)
+        except Exception as e:                          # noqa: BLE001
+            print(f"[rank {rank}] bench_step: {e}", file=sys.stderr)
+        barrier()
 
     out = None
     if rank == 0:
@@ -181,9 +223,25 @@ def main():
                 "achieved": round(path_bytes / elapsed / 1e9, 1), "frac": round(path_bytes / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
                 "kernel_launches_per_step": n_launch, "device_event_us_per_step": round(dev_sec / K * 1e6, 2)}
         if sharded:
-            roofline = {"bound": "hbm", "kernel": "whole step (per-kernel timing hook is single-GPU only)", "achieved": path["achieved"],
+            # where a sharded step goes - streaming kernels, glue, exchanges, and what is left (launch gaps)
+            split = None
+            if shard_steps:
+                iters = 8
+                per = {k: {"us": round(us / n, 3), "launches_per_step": n // iters} for k, (us, _b, n) in shard_steps.items()}
+                stream_us = sum(us for k, (us, _b, n) in shard_steps.items() if k not in ("exchange", "glue")) / iters
+                glue_us = shard_steps.get("glue", (0.0, 0, 0))[0] / iters
+                ex_us = shard_steps.get("exchange", (0.0, 0, 0))[0] / iters
+                gemv_b = sum(_b for k, (us, _b, n) in shard_steps.items() if k in ("qkv", "wo", "w1w3", "w2", "classifier")) / iters
+                gemv_us = sum(us for k, (us, _b, n) in shard_steps.items() if k in ("qkv", "wo", "w1w3", "w2", "classifier")) / iters
+                split = {"stream_us": round(stream_us, 2), "glue_us": round(glue_us, 2),
+                         "exchange_us": round(ex_us, 2) if transport == "p2p" else None,
+                         "gap_us": round(elapsed / K * 1e6 - stream_us - glue_us - (ex_us if transport == "p2p" else 0.0), 2),
+                         "gemv_GBps_this_rank": round(gemv_b / gemv_us / 1e3, 1) if gemv_us else None, "kernels": per,
+                         "note": "rank 0's eager replay of the real step with an event pair per dispatch; a dispatch's duration includes its launch boundary; "
+                                 "exchange_us includes waiting for the slowest peer; with RCCL the collectives carry no events and sit in gap_us"}
+            roofline = {"bound": "hbm", "kernel": "whole sharded step", "achieved": path["achieved"],
                         "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": path["frac"], "traffic": None, "path": path,
-                        "sharded_step_is_one_hipgraph": model.shard_uses_graph()}
+                        "transport": transport, "sharded_step_is_one_hipgraph": model.shard_uses_graph(), "step_split": split}
         else:
           # the real step, replayed eagerly from the live state with an event pair on every dispatch: each kernel's
           # duration as it runs inside the step (real predecessor, real activations, positions W+K+1 ...)
@@ -250,7 +308,7 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine" if args.qtype == "q8_0" else "int4xint4->int32, f32 combine", "data": "synthetic",
             "config": {"workload": f"{cfg.name} {args.qtype.upper()} (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
-                       "parallelism": "single GPU" if world == 1 else f"tp{world}: rows of every weight matrix split over {world} GPUs, RCCL all-gather of the slices",
+                       "parallelism": "single GPU" if world == 1 else f"tp{world}: rows of every weight matrix split over {world} GPUs, slices exchanged by {transport}",
                        "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "prefill": prefill,
         }

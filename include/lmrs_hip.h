@@ -157,9 +157,10 @@ int lmrs_op_expf(int device, float* y, const float* x, size_t n);
 int lmrs_bench_gemv(lmrs_ctx* ctx, int iters, double* us5, double* bytes5, int* count5);
 /* The real decode step at position `pos` (then pos+1, ...) replayed eagerly `iters` times from the context's live state with HIP events on
  * every dispatch: per-kernel durations as they occur INSIDE the step.  kind k: 0 qkv, 1 attention, 2 wo, 3 w1w3, 4 w2, 5 classifier,
- * 6 argmax + next embedding row; us7[k] = summed duration, bytes7[k] = summed algorithmic bytes, count7[k] = launches.
- * Measurement aid, no reference counterpart; the decode state advances by `iters` valid greedy steps. */
-int lmrs_bench_step(lmrs_ctx* ctx, uint32_t pos, int iters, double* us7, double* bytes7, int* count7);
+ * 6 argmax + next embedding row, 7 glue launches of the sharded / unfused forms, 8 peer-to-peer exchanges (time waiting for the peers
+ * included); us9[k] = summed duration, bytes9[k] = summed algorithmic bytes, count9[k] = launches.  On a row-sharded context every
+ * rank calls it together.  Measurement aid, no reference counterpart; the decode state advances by `iters` + 1 valid greedy steps. */
+int lmrs_bench_step(lmrs_ctx* ctx, uint32_t pos, int iters, double* us9, double* bytes9, int* count9);
 /* Debug timeline (LMRS_DEBUG_TIMELINE=1 in the environment at lmrs_create): 8 wall-clock stamps (100 MHz) per
  * kernel of the last decode step, in launch order: [0..3] first workgroup, [4..7] last workgroup:
  * start, prologue done, first rows done, end. */

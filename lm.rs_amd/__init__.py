@@ -216,10 +216,10 @@ class Transformer:
 
     def bench_step(self, pos: int, iters: int = 8):
         """Per-kernel durations of the real decode step (eager replay with events on every dispatch) -> {kind: (us, bytes, launches)}."""
-        us = np.zeros(7, np.float64); b = np.zeros(7, np.float64); n = np.zeros(7, np.int32)
+        us = np.zeros(9, np.float64); b = np.zeros(9, np.float64); n = np.zeros(9, np.int32)
         _chk(lib().lmrs_bench_step(self._h, pos, iters, _p(us), _p(b), _p(n)))
-        names = ("qkv", "attention", "wo", "w1w3", "w2", "classifier", "argmax")
-        return {k: (float(us[i]), float(b[i]), int(n[i])) for i, k in enumerate(names)}
+        names = ("qkv", "attention", "wo", "w1w3", "w2", "classifier", "argmax", "glue", "exchange")
+        return {k: (float(us[i]), float(b[i]), int(n[i])) for i, k in enumerate(names) if n[i]}
 
     def debug_timeline(self):
         """-> uint64[n_kernels, 8] wall-clock stamps (10 ns units) of the last decode step (needs LMRS_DEBUG_TIMELINE=1)."""

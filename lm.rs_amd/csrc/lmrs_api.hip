@@ -17,6 +17,7 @@
 //   activations x[dim], q[att], k_raw[kv], att_out[att], h[hidden], logits[vocab], argmax partials,
 //   tokens[seq_len+1], DevState
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 #include <math.h>
 #include <stdio.h>
@@ -168,6 +169,7 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
     g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+    set_launch_tag(0);
     // Gemma, folded form: the residual lives in x at the top of a layer except that, from layer 1 on, the previous
     // layer's "x += rmsnorm(ffn_out, post_ffn)" (:643-650) is still pending in (x2, tmp): this prologue applies it, x2 -> x.
     const bool pending = c->gemma_fused && l > 0;
@@ -180,24 +182,30 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.seq_len = a.seq_len; t.layer = l;
     t.gemma = gemma; t.st = c->st;
     t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+    set_launch_tag(1);
     if (c->att_split_chunks) HIP_OK(launch_attention_split(t, c->att_S, c->att_split_chunks, c->stream));
     else HIP_OK(launch_attention(t, c->stream));
     // 3. quantize | Wo | x += ...                                       (:550-576)
     g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+    set_launch_tag(2);
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
+    set_launch_tag(7);
     if (gemma && !c->gemma_fused) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
     }
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
     g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     if (c->gemma_fused) { g.delta = c->tmp; g.add_w = L.rms_post_att; g.xout = c->x2; }      // x2 = x + rmsnorm(wo_out, post_att) (:563-568), then pre_ffn norm
+    set_launch_tag(3);
     HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
     g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
     // 5. quantize | W2 | x += ...                                       (:630-654)
     g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+    set_launch_tag(4);
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
+    set_launch_tag(7);
     if (gemma && !c->gemma_fused) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));   // :643-650
     return 0;
 }
@@ -245,7 +253,9 @@ int enqueue_step(lmrs_ctx* c) {
     c->dbg_node = c->dbg_node;   // (nodes numbered in launch order)
     GemvArgs g = cls_args(c);                                   // final rmsnorm + quantize | classifier | argmax partials (:341-381)
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+    set_launch_tag(5);
     HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
+    set_launch_tag(6);
     ArgmaxArgs m{};
     m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.flags = c->flags; m.n_flag_words = c->n_flag_words;
     m.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -270,19 +280,19 @@ int enqueue_step(lmrs_ctx* c) {
 //     their workgroups re-quantising it.  Q4_0 models and LMRS_SHARD_F32_PAYLOAD=1: f32 slices.
 //   * tmp slices (fully row-split form) and the argmax partials: f32 / raw.
 // ------------------------------------------------------------------------------------------------
-struct ExchangeDesc { char* buf; size_t bytes, stride; };     // bytes valid per shard, blocks `stride` bytes apart (in place)
+struct ExchangeDesc { char* buf; size_t bytes, stride; const float* qsrc; size_t qn; };   // bytes valid per shard, blocks `stride` bytes apart (in place); qsrc: f32 slice still to be quantised into this shard's block
 static bool shard_split_out() { static const bool v = getenv("LMRS_SHARD_SPLIT_OUT") != nullptr; return v; }
 
 int n_segments(const lmrs_ctx* c) { return 4 * (int)c->args.n_layers + 2; }
 
 ExchangeDesc exchange_after(lmrs_ctx* c, int seg) {
     const int L4 = 4 * (int)c->args.n_layers;
-    const ExchangeDesc none{nullptr, 0, 0};
-    auto f32s = [](float* p, size_t count) { return ExchangeDesc{reinterpret_cast<char*>(p), count * 4, count * 4}; };
+    const ExchangeDesc none{nullptr, 0, 0, nullptr, 0};
+    auto f32s = [](float* p, size_t count) { return ExchangeDesc{reinterpret_cast<char*>(p), count * 4, count * 4, nullptr, 0}; };
     if (seg < L4) {
         switch (seg & 3) {
-            case 0: return c->qpay ? ExchangeDesc{c->gq_att, (size_t)c->att_dim + (size_t)c->att_dim / 32, c->blk_att} : f32s(c->att_out, (size_t)c->att_dim);
-            case 2: return c->qpay ? ExchangeDesc{c->gq_h, (size_t)c->hid_l + (size_t)c->hid_l / 32, c->blk_h} : f32s(c->h, (size_t)c->hid_l);
+            case 0: return c->qpay ? ExchangeDesc{c->gq_att, (size_t)c->att_dim + (size_t)c->att_dim / 32, c->blk_att, c->p2p ? c->att_out + c->a0 : nullptr, (size_t)c->att_dim} : f32s(c->att_out, (size_t)c->att_dim);
+            case 2: return c->qpay ? ExchangeDesc{c->gq_h, (size_t)c->hid_l + (size_t)c->hid_l / 32, c->blk_h, c->p2p ? c->h + c->h0 : nullptr, (size_t)c->hid_l} : f32s(c->h, (size_t)c->hid_l);
             default: return c->rep_out ? none : f32s(c->tmp, (size_t)c->dim_l);
         }
     }
@@ -299,6 +309,7 @@ int run_segment(lmrs_ctx* c, int seg) {
     g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = gemma; g.st = c->st;
     // the residual update that the PREVIOUS projection left pending
     auto pending_update = [&](const float* norm_w) -> int {
+        set_launch_tag(7);
         if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, norm_w, a.dim, a.rms_norm_eps, c->stream));       // x += rmsnorm(tmp, 1 + w)
         else if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));                      // x += tmp
         return 0;
@@ -308,6 +319,7 @@ int run_segment(lmrs_ctx* c, int seg) {
         g.wq = wq; g.ws = ws; g.n = n; g.o = c->dim_l;
         const bool to_tmp = gemma || !c->rep_out;
         g.out = to_tmp ? c->tmp + c->d0 : c->x;
+        set_launch_tag(n == (int)a.hidden_dim ? 4 : 2);
         int pro = PRO_QUANT;
         if (c->qpay) { pro = PRO_PREQ; g.xq_in = gq; g.preq_slice = slice; g.preq_block = (int)blk; } else g.xin = xin;
         HIP_OK(launch_gemv(g, pro, to_tmp ? EPI_STORE : EPI_RESID, c->stream));
@@ -321,7 +333,9 @@ int run_segment(lmrs_ctx* c, int seg) {
                 g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
                 g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
                 g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
+                set_launch_tag(0);
                 HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_QKV, c->stream));
+                set_launch_tag(1);
                 AttnArgs t{};
                 t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope;
                 t.out = c->att_out + c->a0;
@@ -329,7 +343,8 @@ int run_segment(lmrs_ctx* c, int seg) {
                 t.seq_len = a.seq_len; t.layer = l; t.gemma = gemma; t.st = c->st;
                 if (c->att_split_chunks) HIP_OK(launch_attention_split(t, c->att_S, c->att_split_chunks, c->stream));
                 else HIP_OK(launch_attention(t, c->stream));
-                if (c->qpay) {
+                set_launch_tag(7);
+                if (c->qpay && !c->p2p) {
                     char* blk = c->gq_att + (size_t)c->rank * c->blk_att;
                     HIP_OK(launch_quantize(c->att_out + c->a0, blk, reinterpret_cast<float*>(blk + c->att_dim), c->att_dim, 0, c->stream));
                 }
@@ -341,8 +356,10 @@ int run_segment(lmrs_ctx* c, int seg) {
             case 2:
                 if (pending_update(L.rms_post_att)) return -1;
                 g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * c->hid_l; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h + c->h0;
+                set_launch_tag(3);
                 HIP_OK(launch_gemv(g, PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
-                if (c->qpay) {
+                set_launch_tag(7);
+                if (c->qpay && !c->p2p) {
                     char* blk = c->gq_h + (size_t)c->rank * c->blk_h;
                     HIP_OK(launch_quantize(c->h + c->h0, blk, reinterpret_cast<float*>(blk + c->hid_l), c->hid_l, 0, c->stream));
                 }
@@ -356,9 +373,11 @@ int run_segment(lmrs_ctx* c, int seg) {
     if (seg == L4) {
         if (pending_update(c->layers[a.n_layers - 1].rms_post_ffn)) return -1;
         GemvArgs k = cls_args(c);
+        set_launch_tag(5);
         HIP_OK(launch_gemv(k, PRO_RMS_QUANT, EPI_CLS, c->stream));
         return 0;
     }
+    set_launch_tag(6);
     ArgmaxArgs m{};
     m.part_val = c->part; m.part_idx = reinterpret_cast<const int*>(c->part) + c->cls_grid; m.n_part = c->cls_grid;
     m.n_groups = c->world; m.group_stride = 2 * c->cls_grid;
@@ -399,37 +418,6 @@ int enqueue_step_sharded(lmrs_ctx* c, bool layers_only = false) {
 // reached it.  The arena is fine-grained (uncached in L2) memory, so the kernels that follow read what the peers wrote.
 // Flags are monotonic per (exchange slot of the step, source shard): no reset, no ABA; all shards run the same sequence of steps.
 constexpr int kMaxExchangeSlots = 512;
-struct ExchangeArgs {
-    const char* local; char* peer_dst[8]; unsigned* peer_flag[8]; unsigned* my_flags; unsigned* my_seq; int* err;
-    int bytes, rank, world, slot; long long timeout_ticks;
-};
-__global__ __launch_bounds__(256) void exchange_push_kernel(const ExchangeArgs a) {
-    __shared__ unsigned s_seq;
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_seq = *a.my_seq + 1u; *a.my_seq = s_seq; }
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    for (int w = 0; w < a.world; ++w) {
-        if (w == a.rank) continue;
-        for (int off = tid * 16; off < a.bytes; off += 256 * 16)
-            __builtin_nontemporal_store(*reinterpret_cast<const i32x4*>(a.local + off), reinterpret_cast<i32x4*>(a.peer_dst[w] + off));
-    }
-    __threadfence_system();
-    __syncthreads();
-    const unsigned seq = s_seq;
-    if (tid < a.world && tid != a.rank) {
-        __hip_atomic_store(a.peer_flag[tid], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        const long long t0 = wall_clock64();
-        const bool dead = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // an earlier exchange gave up: do not wait again
-        for (; !dead;) {
-            const unsigned v = __hip_atomic_load(a.my_flags + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((int)(v - seq) >= 0) break;
-            if (wall_clock64() - t0 > a.timeout_ticks) { *a.err = a.slot + 1; break; }    // a peer is gone: report (check_err), do not hang
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __threadfence_system();
-    __syncthreads();
-}
 
 int enqueue_exchange(lmrs_ctx* c, const ExchangeDesc& e) {
     if (c->p2p) {
@@ -445,8 +433,9 @@ int enqueue_exchange(lmrs_ctx* c, const ExchangeDesc& e) {
         x.my_flags = c->xflags + (size_t)c->ex_slot * 8; x.my_seq = c->xseq + c->ex_slot; x.err = c->xerr;
         { static const long long ms = getenv("LMRS_P2P_TIMEOUT_MS") ? atoll(getenv("LMRS_P2P_TIMEOUT_MS")) : 3000; x.timeout_ticks = ms * 100000ll; }   // 100 MHz wall clock
         ++c->ex_slot;
-        hipLaunchKernelGGL(exchange_push_kernel, dim3(1), dim3(256), 0, c->stream, x);
-        HIP_OK(hipGetLastError());
+        if (e.qsrc) { x.qsrc = e.qsrc; x.qn = (int)e.qn; }      // the slice is quantised by the exchange kernel itself on its way out
+        set_launch_tag(8);
+        HIP_OK(launch_exchange_push(x, c->stream));
         return 0;
     }
     if (!c->comm) return fail("this context is a member of a lock-step shard group: drive it with lmrs_group_forward");
@@ -603,7 +592,7 @@ extern "C" int lmrs_p2p_connect(lmrs_ctx* c, const void* handles /* world x 64 b
         float* probe = c->part;
         const float stamp = 1000.0f + (float)c->rank;
         HIP_OK(hipMemcpy(probe + (size_t)c->rank * 64, &stamp, 4, hipMemcpyHostToDevice));
-        const ExchangeDesc e{reinterpret_cast<char*>(probe), 256, 256};
+        const ExchangeDesc e{reinterpret_cast<char*>(probe), 256, 256, nullptr, 0};
         c->ex_slot = kMaxExchangeSlots - 2;
         if (enqueue_exchange(c, e)) return -1;
         c->ex_slot = 0;
@@ -968,7 +957,7 @@ static int step_once(lmrs_ctx* c, uint32_t token, uint32_t pos) {
 extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** logits) {
     if (step_once(c, token, pos)) return -1;
     if (c->world > 1) {                                        // every shard returns the whole logits vector
-        const ExchangeDesc e{reinterpret_cast<char*>(c->logits), (size_t)c->voc_l * 4, (size_t)c->voc_l * 4};
+        const ExchangeDesc e{reinterpret_cast<char*>(c->logits), (size_t)c->voc_l * 4, (size_t)c->voc_l * 4, nullptr, 0};
         const int keep = c->ex_slot; c->ex_slot = kMaxExchangeSlots - 1;      // a slot of its own: the step graph's slots were fixed at capture
         const int rc = enqueue_exchange(c, e);
         c->ex_slot = keep;
@@ -1266,40 +1255,52 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
 // replayed eagerly `iters` times with a (start, stop) event pair on every dispatch: the duration of each kernel of the step as it
 // runs inside the step - after its real predecessor, on the real data.  Decoding continues from the context's current state:
 // call it right after lmrs_generate_greedy; the tokens it produces are valid greedy tokens (and are discarded).
-// kind: 0 qkv, 1 attention, 2 wo, 3 w1w3, 4 w2, 5 classifier, 6 argmax (+ next embedding row).
-extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us7, double* bytes7, int* count7) {
-    if (!c || iters <= 0 || !us7 || !bytes7 || !count7) return fail("bad argument");
-    if (c->world > 1 || c->comm || !c->g_step || c->fused_cls) return fail("lmrs_bench_step: single-GPU contexts (default launch structure) only");
+// kind: 0 qkv, 1 attention, 2 wo, 3 w1w3, 4 w2, 5 classifier, 6 argmax (+ next embedding row), 7 glue launches of the sharded /
+// unfused forms (slice quantise, residual adds), 8 peer-to-peer exchanges (RCCL collectives cannot carry events: 0 there).
+// Row-sharded contexts: every rank must call it (the exchanges wait for the peers).
+extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9, double* bytes9, int* count9) {
+    if (!c || iters <= 0 || !us9 || !bytes9 || !count9) return fail("bad argument");
+    const bool sharded = c->comm || c->p2p;
+    if (c->fused_cls) return fail("lmrs_bench_step: default launch structure only");
+    if (sharded ? !(c->comm || c->p2p_ready) : !c->g_step) return fail("lmrs_bench_step: the context cannot run a step by itself");
     if ((size_t)pos + iters + 1 > c->args.seq_len) return fail("positions out of range");
-    if (c->gemma_fused == false && c->args.model_type == LMRS_GEMMA) return fail("lmrs_bench_step: the unfused Gemma form has extra launches");
     if (c->att_split_pos > 0 && (int)(pos + iters + 1) > c->att_split_pos) return fail("lmrs_bench_step: positions below the split-attention threshold only");
     HIP_OK(hipSetDevice(c->device));
     const lmrs_args& a = c->args;
-    const int nl = (int)a.n_layers, per_step = 5 * nl + 2;
-    std::vector<hipEvent_t> ev(2 * (size_t)per_step);
-    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
-    for (int k = 0; k < 7; ++k) { us7[k] = 0; bytes7[k] = 0; count7[k] = 0; }
-    const double bpe = c->q4 ? 0.5 : 1.0, sc = bpe + 4.0 / 128.0, dim = a.dim, att = c->att_dim, kv = c->kv_dim, hid = a.hidden_dim, V = a.vocab_size;
-    const double wbytes[7] = {dim * (att + 2 * kv) * sc, 0, att * dim * sc, 2 * dim * hid * sc, hid * dim * sc, V * dim * sc, 0};
+    for (int k = 0; k < 9; ++k) { us9[k] = 0; bytes9[k] = 0; count9[k] = 0; }
+    const double bpe = c->q4 ? 0.5 : 1.0, sc = bpe + 4.0 / 128.0, dim = a.dim, att = c->att_dim, kv = c->kv_dim, attf = c->att_full, hidf = a.hidden_dim;
+    const double wbytes[9] = {dim * (att + 2 * kv) * sc, 0, attf * c->dim_l * sc, 2.0 * dim * c->hid_l * sc, hidf * c->dim_l * sc, (double)c->voc_l * dim * sc, 0, 0, 0};
     if (set_state(c, pos, 0)) return -1;
-    int rc = 0;
-    for (int it = -1; it < iters && !rc; ++it) {           // it == -1: untimed (the first eager launches pay one-off costs)
-        set_launch_event_pool(ev.data(), per_step);
-        rc = enqueue_step(c);
+    auto one_step = [&]() -> int { c->ex_slot = 0; return sharded ? enqueue_step_sharded(c) : enqueue_step(c); };
+    // dry pass (also the untimed warm-up: the first eager launches pay one-off costs): how many launches does a step have?
+    hipEvent_t dummy[2]; int dtag[1];
+    HIP_OK(hipEventCreate(&dummy[0])); HIP_OK(hipEventCreate(&dummy[1]));
+    set_launch_event_pool(dummy, 0, dtag);
+    int rc = one_step();
+    const int per_step = launch_event_pool_used();
+    set_launch_event_pool(nullptr, 0);
+    (void)hipEventDestroy(dummy[0]); (void)hipEventDestroy(dummy[1]);
+    if (rc) return -1;
+    HIP_OK(hipStreamSynchronize(c->stream));
+    std::vector<hipEvent_t> ev(2 * (size_t)per_step); std::vector<int> tags(per_step, 0);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    for (int it = 0; it < iters && !rc; ++it) {            // the dry pass was position `pos`; the timed ones follow it
+        set_launch_event_pool(ev.data(), per_step, tags.data());
+        rc = one_step();
         const int used = launch_event_pool_used();
         set_launch_event_pool(nullptr, 0);
         if (rc) break;
         HIP_OK(hipStreamSynchronize(c->stream));
         if (used != per_step) { rc = fail("lmrs_bench_step: the step did not have the expected number of launches"); break; }
-        if (it < 0) continue;                                            // the untimed pass was position `pos`; the timed ones follow it
         for (int i = 0; i < per_step; ++i) {
             float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-            const int kind = i < 5 * nl ? i % 5 : (i == 5 * nl ? 5 : 6);
-            us7[kind] += (double)ms * 1e3; count7[kind] += 1;
-            bytes7[kind] += kind == 1 ? 2.0 * kv * 4 * ((double)pos + it + 3) : wbytes[kind];     // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
+            const int kind = tags[i] >= 0 && tags[i] < 9 ? tags[i] : 7;
+            us9[kind] += (double)ms * 1e3; count9[kind] += 1;
+            bytes9[kind] += kind == 1 ? 2.0 * kv * 4 * ((double)pos + it + 3) : wbytes[kind];     // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
         }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
+    if (!rc && check_err(c)) rc = -1;
     return rc;
 }
 

@@ -77,8 +77,10 @@ struct ArgmaxArgs {
 // launches (all asynchronous on `s`)
 hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint = 0);
 void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop);   // measurement: attach events to the next GEMV dispatches (null: off)
-void set_launch_event_pool(hipEvent_t* pairs, int n_pairs);       // measurement: (start, stop) pairs for every following launch, in launch order (null: off)
-int launch_event_pool_used();
+void set_launch_event_pool(hipEvent_t* pairs, int n_pairs, int* tags = nullptr);   // measurement: (start, stop) pairs for every following launch, in launch order (null: off)
+void set_launch_tag(int tag);                                     // ... each labelled with the tag current at its launch
+int launch_event_pool_used();                                     // launches seen since the pool was set (may exceed n_pairs)
+bool next_launch_events(hipEvent_t* a, hipEvent_t* b);            // for launches made outside lmrs_kernels.hip
 int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
 bool gemv_is_static(const GemvArgs& a, int pro, int epi); // a compile-time-shape kernel exists for this launch
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
@@ -98,6 +100,18 @@ hipError_t launch_softmax(float* x, int n, hipStream_t st);
 hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st);
 
 constexpr int kMaxArgmaxParts = 4096;
+
+// ---- peer-to-peer exchange of the row-sharded step (exchange_push_kernel)
+struct ExchangeArgs {
+    const char* local;            // my block in my arena
+    char* peer_dst[8];            // the same place in every peer's arena
+    unsigned* peer_flag[8];       // my flag word in every peer's flag row of this slot
+    unsigned* my_flags;           // my flag row of this slot (one word per source shard)
+    unsigned* my_seq; int* err;
+    int bytes, rank, world, slot; long long timeout_ticks;
+    const float* qsrc; int qn;    // optional: f32 slice to quantise (Q8_0) into `local` first: [qn int8 | qn / 128 f32 scales]
+};
+hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s);
 
 // ---- batched forward_layer (lmrs_prefill.inc): matmul_q8 over n_tok tokens on the int8 matrix cores
 struct GemmArgs {

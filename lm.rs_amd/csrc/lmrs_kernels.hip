@@ -666,10 +666,17 @@ void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop) { t_ev_start = st
 // ... or a pool of (start, stop) pairs handed out to EVERY launch of the decode step in launch order (GEMVs, attention, argmax):
 // an eager replay of the real step then yields the duration of each of its kernels (lmrs_bench_step).
 static thread_local hipEvent_t* t_ev_pool = nullptr; static thread_local int t_ev_cap = 0, t_ev_used = 0;
-void set_launch_event_pool(hipEvent_t* pairs, int n_pairs) { t_ev_pool = pairs; t_ev_cap = n_pairs; t_ev_used = 0; }
+static thread_local int* t_ev_tags = nullptr; static thread_local int t_ev_tag = 0;      // the caller's label for the launches that follow
+void set_launch_event_pool(hipEvent_t* pairs, int n_pairs, int* tags) { t_ev_pool = pairs; t_ev_cap = n_pairs; t_ev_used = 0; t_ev_tags = tags; t_ev_tag = 0; }
+void set_launch_tag(int tag) { t_ev_tag = tag; }
 int launch_event_pool_used() { return t_ev_used; }
-static bool next_launch_events(hipEvent_t* a, hipEvent_t* b) {
-    if (t_ev_pool && t_ev_used < t_ev_cap) { *a = t_ev_pool[2 * t_ev_used]; *b = t_ev_pool[2 * t_ev_used + 1]; ++t_ev_used; return true; }
+bool next_launch_events(hipEvent_t* a, hipEvent_t* b) {
+    if (t_ev_pool && t_ev_used < t_ev_cap) {
+        *a = t_ev_pool[2 * t_ev_used]; *b = t_ev_pool[2 * t_ev_used + 1];
+        if (t_ev_tags) t_ev_tags[t_ev_used] = t_ev_tag;
+        ++t_ev_used; return true;
+    }
+    if (t_ev_pool) { ++t_ev_used; return false; }                                           // pool exhausted: keep counting (the caller sizes it from a dry pass)
     if (t_ev_start) { *a = t_ev_start; *b = t_ev_stop; return true; }
     return false;
 }
@@ -1408,14 +1415,14 @@ hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hip
     if (n % kGS || n > kMaxP * 1024) return hipErrorInvalidValue;
     if (!q4 && (n == 2048 || n == 3072 || n == 8192)) {
         int8_t* q8 = static_cast<int8_t*>(q);
-        if (n == 2048) hipLaunchKernelGGL((quantize_static_kernel<2048, 256>), dim3(1), dim3(256), 0, st, x, q8, s);
-        else if (n == 3072) hipLaunchKernelGGL((quantize_static_kernel<3072, 256>), dim3(1), dim3(256), 0, st, x, q8, s);
-        else hipLaunchKernelGGL((quantize_static_kernel<8192, 512>), dim3(1), dim3(512), 0, st, x, q8, s);
+        if (n == 2048) LMRS_LAUNCH_GRID((quantize_static_kernel<2048, 256>), dim3(1), 256, 0, st, x, q8, s);
+        else if (n == 3072) LMRS_LAUNCH_GRID((quantize_static_kernel<3072, 256>), dim3(1), 256, 0, st, x, q8, s);
+        else LMRS_LAUNCH_GRID((quantize_static_kernel<8192, 512>), dim3(1), 512, 0, st, x, q8, s);
         return hipGetLastError();
     }
     const size_t smem = ((n + 15) & ~15) + (size_t)(n / kGS + 4) * 4;
-    if (q4) hipLaunchKernelGGL(quantize_kernel<true>, dim3(1), dim3(kBlock), smem, st, x, q, s, n);
-    else hipLaunchKernelGGL(quantize_kernel<false>, dim3(1), dim3(kBlock), smem, st, x, q, s, n);
+    if (q4) LMRS_LAUNCH_GRID(quantize_kernel<true>, dim3(1), kBlock, smem, st, x, q, s, n);
+    else LMRS_LAUNCH_GRID(quantize_kernel<false>, dim3(1), kBlock, smem, st, x, q, s, n);
     return hipGetLastError();
 }
 
@@ -1466,7 +1473,7 @@ __global__ __launch_bounds__(kBlock) void addnorm_kernel(float* x, const float* 
 hipError_t launch_addnorm(float* x, const float* delta, const float* w, int n, float eps, hipStream_t st) {
     if (n % 32 || n > kMaxP * 1024) return hipErrorInvalidValue;
     const size_t smem = (size_t)(8 * (n / 8 + 4) + 4) * 4;
-    hipLaunchKernelGGL(addnorm_kernel, dim3(1), dim3(kBlock), smem, st, x, delta, w, n, eps);
+    LMRS_LAUNCH_GRID(addnorm_kernel, dim3(1), kBlock, smem, st, x, delta, w, n, eps);
     return hipGetLastError();
 }
 
@@ -1480,7 +1487,7 @@ __global__ void addvec_kernel(float* x, const float* d, int n) {
     }
 }
 hipError_t launch_addvec(float* x, const float* d, int n, hipStream_t st) {
-    hipLaunchKernelGGL(addvec_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, st, x, d, n);
+    LMRS_LAUNCH_GRID(addvec_kernel, dim3((n / 4 + 255) / 256), 256, 0, st, x, d, n);
     return hipGetLastError();
 }
 
@@ -1518,6 +1525,60 @@ __global__ void expf_kernel(const float* x, float* y, size_t n) {
 
 hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(expf_kernel, dim3(1024), dim3(256), 0, st, x, y, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Peer-to-peer exchange of the row-sharded step (the alternative to ncclAllGather for these latency-bound, few-KB messages).
+// One workgroup: [quantise my f32 slice into my block (quantization.rs:44-67; whole 128-groups, so bit-identical to quantising the
+// gathered vector) -] copy my block into the same place of every peer's exchange arena (stores that leave over xGMI; in the
+// single-device verification modes the "peers" are other contexts / processes on the same GPU), make them visible system-wide,
+// raise my flag in every peer's flag row with this exchange's sequence number, then wait until every peer's flag in MY row has
+// reached it.  The arena is fine-grained (uncached in L2) memory, so the kernels that follow read what the peers wrote.
+// Flags are monotonic per (exchange slot of the step, source shard): no reset, no ABA; all shards run the same sequence of steps.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void exchange_push_kernel(const ExchangeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned s_seq;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_seq = *a.my_seq + 1u; *a.my_seq = s_seq; }
+    if (a.qsrc) {                                          // my slice, quantised on its way out: [qn int8 | qn / 128 scales]
+        int8_t* xq = reinterpret_cast<int8_t*>(smem);
+        float* xs = reinterpret_cast<float*>(smem + ((a.qn + 15) & ~15));
+        float4 v[kMaxP];
+        load_vec(v, a.qsrc, a.qn);
+        char* blk = const_cast<char*>(a.local);
+        quantize_to_lds<false, kMaxP>(v, a.qn, xq, xs, blk, reinterpret_cast<float*>(blk + a.qn));
+        __threadfence();                                   // the block is re-read below by other lanes of this workgroup
+    }
+    __syncthreads();
+    for (int w = 0; w < a.world; ++w) {
+        if (w == a.rank) continue;
+        for (int off = tid * 16; off < a.bytes; off += kBlock * 16)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.local + off)), reinterpret_cast<i32x4*>(a.peer_dst[w] + off));
+    }
+    __threadfence_system();
+    __syncthreads();
+    const unsigned seq = s_seq;
+    if (tid < a.world && tid != a.rank) {
+        __hip_atomic_store(a.peer_flag[tid], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        const bool dead = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // an earlier exchange gave up: do not wait again
+        for (; !dead;) {
+            const unsigned v = __hip_atomic_load(a.my_flags + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(v - seq) >= 0) break;
+            if (wall_clock64() - t0 > a.timeout_ticks) { *a.err = a.slot + 1; break; }    // a peer is gone: report (check_err), do not hang
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+}
+
+hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s) {
+    if (a.qsrc && (a.qn % kGS || a.qn > kMaxP * 1024)) return hipErrorInvalidValue;
+    const size_t smem = a.qsrc ? ((a.qn + 15) & ~15) + (size_t)(a.qn / kGS + 4) * 4 : 16;
+    LMRS_LAUNCH_GRID(exchange_push_kernel, dim3(1), kBlock, smem, s, a);
     return hipGetLastError();
 }
 

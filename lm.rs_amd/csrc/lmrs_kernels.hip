@@ -504,6 +504,8 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     WTile<R::U> ta, tb;
     int pass = blockIdx.x;                      // grid <= n_pass
     tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(pass));
+    // (requesting the second pass's tile here as well - it would stream under the prologue - was measured slower on every model, Gemma's
+    // 5 us folded prologue included: the more bytes are queued ahead of a workgroup's activation loads, the later they land)
     // Epilogue operands that live in memory are fetched here, under the prologue, instead of as a dependent round trip at
     // the very end of the kernel: the residual value of the first pass's row (each row has exactly one writer, nobody else
     // touches it during the launch) and the position the QKV epilogue stores the V row at.
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     LMRS_STAMP0(1);
 
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;   // EPI_CLS
-    const bool writer = r >= L - R::CL && (r % R::CL) == 0;                // one lane of the row's last cluster
+    const bool writer = r == R::WR;                                        // the lane of the row that holds the finished sum
 
     auto finish = [&](float acc, int ps) __attribute__((always_inline)) {
         const int row = ps * R::RB + wave * R::RW + lane / L;
@@ -575,6 +577,38 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
         }
     };
 
+    if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GELU) {
+        // Gate/up launches: the activation (SiLU: glibc expf in double; GELU: an f64 tanh, ~230 instructions) costs the WAVE its
+        // whole instruction stream however few lanes need it, and only one lane in 2L holds a (gate, up) pair.  So the passes are
+        // taken two at a time: the second pass's pair moves one lane up (DPP row_shr:1, same 16-lane row) and ONE evaluation serves both.
+        for (;;) {
+            const int p1 = pass + gridDim.x;
+            const bool have1 = p1 < n_pass;
+            if (have1) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));
+            const float acc_a = tile_consume<N, L, Q4>(ta, xq, xs);
+            if (pass == (int)blockIdx.x) LMRS_STAMP0(2);
+            const int p2 = p1 + gridDim.x;
+            const bool have2 = have1 && p2 < n_pass;
+            float acc_b = 0.0f;
+            if (have1) {                                                   // wave-uniform
+                if (have2) tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(p2));
+                acc_b = tile_consume<N, L, Q4>(tb, xq, xs);
+            }
+            const float up_a = __shfl_down(acc_a, L), up_b = __shfl_down(acc_b, L);          // rows interleaved: 2i gate, 2i+1 up
+            const float gate_b1 = dpp_f<0x111>(acc_b), up_b1 = dpp_f<0x111>(up_b);           // pass B's pair, one lane up
+            const bool lane_a = writer && ((lane / L) & 1) == 0;                            // holds pass A's pair
+            const bool lane_b = have1 && (r == R::WR + 1) && ((lane / L) & 1) == 0;         // its neighbour: pass B's pair
+            const float gate = lane_b ? gate_b1 : acc_a, up = lane_b ? up_b1 : up_a;
+            float hval;
+            if constexpr (EPI == EPI_SWIGLU) hval = swiglu_t(gate, up, etab);               // all lanes (expf shuffles its table)
+            else hval = (lane_a || lane_b) ? geglu(gate, up) : 0.0f;
+            const int row_a = pass * R::RB + wave * R::RW + lane / L, row_b = p1 * R::RB + wave * R::RW + lane / L;
+            if (lane_a && row_a < o) a.out[row_a >> 1] = hval;
+            if (lane_b && row_b < o) a.out[row_b >> 1] = hval;
+            if (!have2) break;
+            pass = p2;
+        }
+    } else
     // double-buffered passes
     for (;;) {
         const int p1 = pass + gridDim.x;

@@ -70,8 +70,16 @@ __device__ __forceinline__ void vec_load(float4 (&v)[(VecGeom<N, NTH>::NP)], con
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int e = i * VecGeom<N, NTH>::PER + (int)threadIdx.x * 4;
-        if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) v[i] = ld_f32x4<COH>(x + e);
-        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (VecGeom<N, NTH>::FULL) v[i] = ld_f32x4<COH>(x + e);
+        else if (i < NP - 1) v[i] = ld_f32x4<COH>(x + e);
+        else {
+            // ragged last pass (N = 2304, 9216): the load stays UNCONDITIONAL on a clamped address and the lanes past the end are
+            // zeroed by a select - a load under a lane predicate makes hipcc wait for ALL outstanding loads (vmcnt(0)) right there,
+            // i.e. before the weight tile is even requested (measured: x landed at 2.9 us instead of 0.7 in the Gemma prologues)
+            const bool live = e < N;
+            const float4 t4 = ld_f32x4<COH>(x + (live ? e : N - 4));
+            v[i] = live ? t4 : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 
@@ -269,6 +277,12 @@ template <int N, int L, int NTH = kBlk, bool Q4 = false> struct RowGeom {
     static constexpr int RW = 64 / L, RB = RW * (NTH / 64);        // rows per wave / per workgroup pass
     static_assert(L % CL == 0 && G % NC == 0, "row groups must divide over the clusters");
     static_assert(U >= 1 && U <= 24, "a cluster's groups must fit one tile");
+    // Q4_0: a group is only 64 bytes, half a cache line.  Two clusters form a PAIR (8 aligned lanes) that owns a contiguous segment
+    // of 2 * U groups and takes them alternately (even groups: first cluster, odd: second), so that one load instruction reads
+    // 8 lanes x 16 B = one whole 128-byte line per pair.  (With a contiguous segment per cluster every instruction touched twice
+    // as many lines, half of each: the Q4_0 streams ran at half the byte rate of the Q8_0 ones.)
+    static_assert(!Q4 || (L % 8 == 0), "Q4_0: lanes per row in pairs of clusters");
+    static constexpr int WR = Q4 ? L - 8 : L - CL;                // first lane of the row that holds the finished sum
 };
 
 template <int U> struct WTile { i32x4 w[U]; float sc[U]; };
@@ -277,22 +291,65 @@ template <int U> struct WTile { i32x4 w[U]; float sc[U]; };
 template <int N, int L, bool Q4 = false, int U0 = 0, int U1 = RowGeom<N, L, kBlk, Q4>::U>
 __device__ __forceinline__ void tile_issue(WTile<RowGeom<N, L, kBlk, Q4>::U>& t, const int8_t* __restrict__ wq, const float* __restrict__ ws, int row) {
     using R = RowGeom<N, L, kBlk, Q4>;
-    const int lane = threadIdx.x & 63, r = lane % L, g0 = (r / R::CL) * R::U, rc = r % R::CL;
-    const LMRS_GLOBAL i32x4* wrow = as_global(reinterpret_cast<const i32x4*>(wq + (size_t)row * R::ROWB)) + g0 * R::CL + rc;
-    const LMRS_GLOBAL float* srow = as_global(ws) + (size_t)row * R::G + g0;
+    const int lane = threadIdx.x & 63, r = lane % L;
+    if constexpr (!Q4) {
+        const int g0 = (r / R::CL) * R::U, rc = r % R::CL;
+        const LMRS_GLOBAL i32x4* wrow = as_global(reinterpret_cast<const i32x4*>(wq + (size_t)row * R::ROWB)) + g0 * R::CL + rc;
+        const LMRS_GLOBAL float* srow = as_global(ws) + (size_t)row * R::G + g0;
 #pragma unroll
-    for (int u = U0; u < U1; ++u) {
-        t.w[u] = __builtin_nontemporal_load(wrow + u * R::CL);
-        t.sc[u] = srow[u];
+        for (int u = U0; u < U1; ++u) {
+            t.w[u] = __builtin_nontemporal_load(wrow + u * R::CL);
+            t.sc[u] = srow[u];
+        }
+    } else {                                                       // pair-interleaved: step u = group seg0 + 2u + sub
+        const int seg0 = (r / 8) * 2 * R::U, sub = (r >> 2) & 1, rc = r & 3;
+        const LMRS_GLOBAL i32x4* wrow = as_global(reinterpret_cast<const i32x4*>(wq + (size_t)row * R::ROWB)) + (seg0 + sub) * 4 + rc;
+        const LMRS_GLOBAL float* srow = as_global(ws) + (size_t)row * R::G + seg0 + sub;
+#pragma unroll
+        for (int u = U0; u < U1; ++u) {
+            t.w[u] = __builtin_nontemporal_load(wrow + u * 8);
+            t.sc[u] = srow[2 * u];
+        }
     }
 }
 
-// -> the row's result, valid in the lanes of the row's LAST cluster (r >= L - CL).
+// -> the row's result, valid in lane R::WR of the row (Q8_0: the whole last cluster; Q4_0: the first cluster of the last pair).
 template <int N, int L, bool Q4 = false>
 __device__ __forceinline__ float tile_consume(const WTile<RowGeom<N, L, kBlk, Q4>::U>& t, const int8_t* xq, const float* xs) {
     using R = RowGeom<N, L, kBlk, Q4>;
     const int lane = threadIdx.x & 63, r = lane % L, cl = r / R::CL, g0 = cl * R::U, rc = r % R::CL;
     float pb[R::U];
+    if constexpr (Q4) {
+        // pair-interleaved layout (RowGeom): this lane's step u is group seg0 + 2u + sub; the chain runs in the pair's first cluster,
+        // which takes its own product, then its neighbour's (DPP row_shl:4, fetched while every lane is active), group by group
+        const int rp = r / 8, seg0 = rp * 2 * R::U, sub = (r >> 2) & 1;
+        float nb[R::U];
+#pragma unroll
+        for (int u = 0; u < R::U; ++u) {
+            const int g = seg0 + 2 * u + sub;
+            const i32x4 x = *reinterpret_cast<const i32x4*>(xq + (g * 4 + rc) * 16);
+            int d = __builtin_amdgcn_sdot8(t.w[u].x ^ (int)0x88888888, x.x, 0, false);
+            d = __builtin_amdgcn_sdot8(t.w[u].y ^ (int)0x88888888, x.y, d, false);
+            d = __builtin_amdgcn_sdot8(t.w[u].z ^ (int)0x88888888, x.z, d, false);
+            d = __builtin_amdgcn_sdot8(t.w[u].w ^ (int)0x88888888, x.w, d, false);
+            d += dpp_i<0xB1>(d); d += dpp_i<0x4E>(d);             // the 4 lanes of the cluster
+            const float p = (float)d * t.sc[u];                    // (ival as f32) * w.s[..]
+            pb[u] = p * xs[g];                                     //   * x.s[..]
+        }
+#pragma unroll
+        for (int u = 0; u < R::U; ++u) nb[u] = dpp_f<0x104>(pb[u]);   // row_shl:4: the odd group's product, into the chain lanes
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < L / 8; ++j) {
+            const float carry = j == 0 ? 0.0f : __shfl(acc, (lane & ~(L - 1)) + (j - 1) * 8);
+            if (rp == j && sub == 0) {
+                acc = carry;
+#pragma unroll
+                for (int u = 0; u < R::U; ++u) { acc = acc + pb[u]; acc = acc + nb[u]; }      // xout += ..., groups ascending
+            }
+        }
+        return acc;
+    }
 #pragma unroll
     for (int u = 0; u < R::U; ++u) {
         const i32x4 x = *reinterpret_cast<const i32x4*>(xq + ((g0 + u) * R::CL + rc) * 16);

@@ -79,7 +79,7 @@ struct lmrs_ctx {
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
-    bool q4 = false;
+    bool q4 = false, f32 = false;                  // f32: q_type None (unquantised weights, lmrs_f32.inc)
     // ---- row sharding.  Every shard owns whole output rows, so every float accumulation chain
     // lives on one GPU and results are bit-identical to world == 1.
     int rank = 0, world = 1;
@@ -147,8 +147,43 @@ void rope_terms(const lmrs_args& a, uint32_t p, uint32_t j, float* fcr, float* f
     *fci = sinf(val) * scaling_factor;
 }
 
+// one decoder layer of an unquantised model (q_type None): the same launches with the f32 matmul (lmrs_f32.inc); Gemma's
+// x += rmsnorm(branch) steps as separate launches
+int enqueue_layer_f32(lmrs_ctx* c, int l) {
+    const lmrs_args& a = c->args;
+    const DevLayer& L = c->layers[l];
+    const bool gemma = a.model_type == LMRS_GEMMA;
+    GemvArgs g{};
+    g.eps = a.rms_norm_eps; g.add_unit = gemma; g.st = c->st;
+    g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
+    set_launch_tag(0);
+    g.wq = L.wqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim; g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
+    HIP_OK(launch_gemv_f32(g, PRO_RMS_QUANT, EPI_QKV, c->stream));
+    AttnArgs t{};
+    t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->att_out;
+    t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.seq_len = a.seq_len; t.layer = l; t.gemma = gemma; t.st = c->st;
+    set_launch_tag(1);
+    if (c->att_split_chunks) HIP_OK(launch_attention_split(t, c->att_S, c->att_split_chunks, c->stream));
+    else HIP_OK(launch_attention(t, c->stream));
+    set_launch_tag(2);
+    g.wq = L.wo; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
+    HIP_OK(launch_gemv_f32(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
+    set_launch_tag(7);
+    if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));
+    set_launch_tag(3);
+    g.wq = L.w13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
+    HIP_OK(launch_gemv_f32(g, PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
+    set_launch_tag(4);
+    g.wq = L.w2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = gemma ? c->tmp : c->x;
+    HIP_OK(launch_gemv_f32(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
+    set_launch_tag(7);
+    if (gemma) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));
+    return 0;
+}
+
 // one decoder layer (transformer.rs:388-657) as 5 fused launches
 int enqueue_layer(lmrs_ctx* c, int l) {
+    if (c->f32) return enqueue_layer_f32(c, l);
     const lmrs_args& a = c->args;
     const DevLayer& L = c->layers[l];
     const bool gemma = a.model_type == LMRS_GEMMA;
@@ -224,8 +259,8 @@ GemvArgs cls_args(lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     GemvArgs g{};
     g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = a.model_type == LMRS_GEMMA; g.st = c->st;
-    const size_t row_bytes = c->q4 ? a.dim / 2 : a.dim;
-    g.wq = static_cast<const char*>(c->cls_q) + (size_t)c->v0 * row_bytes; g.ws = c->cls_s + (size_t)c->v0 * (a.dim / 128);
+    const size_t row_bytes = c->f32 ? (size_t)a.dim * 4 : (c->q4 ? a.dim / 2 : a.dim);
+    g.wq = static_cast<const char*>(c->cls_q) + (size_t)c->v0 * row_bytes; g.ws = c->f32 ? nullptr : c->cls_s + (size_t)c->v0 * (a.dim / 128);
     g.n = a.dim; g.o = c->voc_l; g.xin = c->x; g.rms_w = c->rms_final; g.row_offset = c->v0;
     g.out = c->logits + c->v0;
     if (c->world > 1 || c->comm) {          // sharded: this shard's [values | indices] block of the gathered partials
@@ -240,7 +275,7 @@ GemvArgs cls_args(lmrs_ctx* c) {
 EmbedArgs embed_args(lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     EmbedArgs e{};
-    e.emb_q = c->emb_q; e.emb_s = c->emb_s; e.q4 = c->q4; e.tokens = c->tokens; e.x = c->x; e.dim = a.dim;
+    e.emb_q = c->emb_q; e.emb_s = c->emb_s; e.q4 = c->f32 ? 2 : (int)c->q4; e.tokens = c->tokens; e.x = c->x; e.dim = a.dim;
     e.do_scale = a.model_type == LMRS_GEMMA; e.scale = sqrtf((float)a.dim); e.st = c->st;
     return e;
 }
@@ -254,7 +289,8 @@ int enqueue_step(lmrs_ctx* c) {
     GemvArgs g = cls_args(c);                                   // final rmsnorm + quantize | classifier | argmax partials (:341-381)
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     set_launch_tag(5);
-    HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
+    if (c->f32) HIP_OK(launch_gemv_f32(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
+    else HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
     set_launch_tag(6);
     ArgmaxArgs m{};
     m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.flags = c->flags; m.n_flag_words = c->n_flag_words;
@@ -662,8 +698,9 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     Layout lay; std::string perr;
     if (!parse_layout(file, len, &lay, &perr)) return fail(perr);
     const lmrs_args& a = lay.args;
-    if (a.q_type == LMRS_Q_NONE) return fail("q_type None (f32 weights) is not on the HIP hot path; quantised LMRS files only");
-    if (a.group_size != 128) return fail("group_size != 128 is not supported by the HIP kernels (the reference exporter always quantises with 128)");
+    const bool f32w = a.q_type == LMRS_Q_NONE;
+    if (f32w && (world > 1 || uid)) return fail("q_type None (f32 weights) runs on one GPU only (row sharding is built for the quantised path)");
+    if (!f32w && a.group_size != 128) return fail("group_size != 128 is not supported by the HIP kernels (the reference exporter always quantises with 128)");
     const size_t dim = a.dim, att = (size_t)a.n_heads * a.head_size, kv = (size_t)a.n_kv_heads * a.head_size, hid = a.hidden_dim, V = a.vocab_size;
     if (dim % 128 || att % 128 || hid % 128) return fail("dim, n_heads*head_size and hidden_dim must be multiples of 128");
     if (dim > 10240 || att > 10240 || hid > 16384) return fail("vector lengths above 10240 (dim, attention) / 16384 (hidden) are not supported");
@@ -689,7 +726,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     (void)hs;
 
     lmrs_ctx* c = new lmrs_ctx();
-    c->args = a; c->lay = lay; c->device = device; c->q4 = a.q_type == LMRS_Q4_0;
+    c->args = a; c->lay = lay; c->device = device; c->q4 = a.q_type == LMRS_Q4_0; c->f32 = f32w;
     c->rank = rank; c->world = world; c->att_full = (int)att;
     c->att_dim = (int)att_l; c->kv_dim = (int)kv_l; c->dim_l = (int)dim_l; c->hid_l = (int)hid_l; c->voc_l = (int)voc_l;
     c->a0 = (int)a0; c->d0 = (int)d0; c->h0 = (int)h0; c->v0 = (int)v0;
@@ -709,9 +746,9 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         if (nr != ncclSuccess) { fail(std::string("ncclCommInitRank: ") + ncclGetErrorString(nr)); return cleanup(); }
     }
 
-    const size_t G = 128, bpe_num = c->q4 ? 1 : 2;   // bytes per element = bpe_num / 2
+    const size_t G = 128, bpe_num = f32w ? 8 : (c->q4 ? 1 : 2);   // bytes per element = bpe_num / 2 (f32 weights: 4, no scales)
     auto qbytes = [&](size_t rows, size_t cols) { return rows * cols * bpe_num / 2; };
-    auto sbytes = [&](size_t rows, size_t cols) { return rows * cols / G * 4; };
+    auto sbytes = [&](size_t rows, size_t cols) { return f32w ? (size_t)0 : rows * cols / G * 4; };
     const size_t nl = a.n_layers;
     size_t total = 0;
     auto need = [&](size_t b) { total += pad256(b); };
@@ -742,6 +779,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
 
     // ---- weights: this shard's rows only (the embedding / classifier table stays whole: any row may be looked up)
     auto upload_rows = [&](void* dst, const TensorView& tv, size_t row0, size_t nrows, size_t cols, bool scales) -> int {
+        if (scales && f32w) return 0;
         const size_t rb = scales ? cols / G * 4 : qbytes(1, cols);
         return upload(c, dst, file + (scales ? tv.s_off : tv.q_off) + row0 * rb, nrows * rb);
     };
@@ -766,8 +804,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         CK(upload_rows(so, lay.wo[l], d0, dim_l, att, true));
         CK(upload_interleaved(c, w13, file + lay.w1[l].q_off + h0 * rb, rb, hid_l, 0));
         CK(upload_interleaved(c, w13, file + lay.w3[l].q_off + h0 * rb, rb, hid_l, 1));
-        CK(upload_interleaved(c, s13, file + lay.w1[l].s_off + h0 * srb, srb, hid_l, 0));
-        CK(upload_interleaved(c, s13, file + lay.w3[l].s_off + h0 * srb, srb, hid_l, 1));
+        if (!f32w) { CK(upload_interleaved(c, s13, file + lay.w1[l].s_off + h0 * srb, srb, hid_l, 0)); CK(upload_interleaved(c, s13, file + lay.w3[l].s_off + h0 * srb, srb, hid_l, 1)); }
         CK(upload_rows(w2, lay.w2[l], d0, dim_l, hid, false));
         CK(upload_rows(s2, lay.w2[l], d0, dim_l, hid, true));
         CK(upload(c, r0, file + lay.rms_att[l].q_off, dim * 4));
@@ -782,12 +819,12 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     {
         char* eq = c->alloc<char>(lay.emb.q_bytes); float* es = c->alloc<float>(lay.emb.s_bytes / 4);
         if (!eq || !es) { fail("arena overflow"); return cleanup(); }
-        CK(upload(c, eq, file + lay.emb.q_off, lay.emb.q_bytes)); CK(upload(c, es, file + lay.emb.s_off, lay.emb.s_bytes));
+        CK(upload(c, eq, file + lay.emb.q_off, lay.emb.q_bytes)); if (!f32w) CK(upload(c, es, file + lay.emb.s_off, lay.emb.s_bytes));
         c->emb_q = eq; c->emb_s = es; c->cls_q = eq; c->cls_s = es;        // tied classifier = the QUANTISED table
         if (a.model_type == LMRS_PHI) {
             char* hq = c->alloc<char>(lay.lm_head.q_bytes); float* hsx = c->alloc<float>(lay.lm_head.s_bytes / 4);
             if (!hq || !hsx) { fail("arena overflow"); return cleanup(); }
-            CK(upload(c, hq, file + lay.lm_head.q_off, lay.lm_head.q_bytes)); CK(upload(c, hsx, file + lay.lm_head.s_off, lay.lm_head.s_bytes));
+            CK(upload(c, hq, file + lay.lm_head.q_off, lay.lm_head.q_bytes)); if (!f32w) CK(upload(c, hsx, file + lay.lm_head.s_off, lay.lm_head.s_bytes));
             c->cls_q = hq; c->cls_s = hsx;
         }
         float* rf = c->alloc<float>(dim);
@@ -852,7 +889,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     HCK(hipHostMalloc(reinterpret_cast<void**>(&c->h_err), 4, hipHostMallocDefault));
     CK(set_state(c, 0, 0));
     HCK(hipStreamSynchronize(c->stream));
-    if (a.model_type == LMRS_GEMMA && !sharded && !getenv("LMRS_GEMMA_UNFUSED")) {
+    if (a.model_type == LMRS_GEMMA && !sharded && !f32w && !getenv("LMRS_GEMMA_UNFUSED")) {
         // fold the two "x += rmsnorm(branch)" steps of a Gemma layer into the consuming GEMV prologues when every launch of the
         // step has a static kernel that can do it (otherwise: the separate addnorm launches)
         GemvArgs q{}; q.q4 = c->q4; q.n = a.dim; q.o = c->att_dim + 2 * c->kv_dim;
@@ -863,7 +900,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     }
     {
         GemvArgs g = cls_args(c);
-        c->cls_grid = gemv_grid(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS);
+        c->cls_grid = f32w ? gemv_f32_grid(g, EPI_CLS) : gemv_grid(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS);
     }
     if (!sharded) {
         CK(capture(c, true, &c->g_step));
@@ -989,7 +1026,7 @@ extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, s
         const size_t m = n - i0 < chunk ? n - i0 : chunk;
         for (size_t i = 0; i < m; ++i) if (tokens[i0 + i] >= c->args.vocab_size) return fail("token out of range");
         HIP_OK(hipMemcpyAsync(dtok, tokens + i0, m * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_OK(launch_dequant_rows(c->emb_q, c->emb_s, c->q4, dtok, (int)m, (int)dim, c->stage, c->stream));
+        HIP_OK(launch_dequant_rows(c->emb_q, c->emb_s, c->f32 ? 2 : (int)c->q4, dtok, (int)m, (int)dim, c->stage, c->stream));
         HIP_OK(hipMemcpyAsync(out + i0 * dim, c->stage, m * dim * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
     }
@@ -1193,7 +1230,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
 // Infinity Cache), each launch carrying its own start/stop HIP events (hipExtLaunchKernelGGL) on the context's stream.
 extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* bytes5, int* count5) {
     if (!c || iters <= 0 || !us5 || !bytes5 || !count5) return fail("bad argument");
-    if (c->world > 1 || c->comm) return fail("lmrs_bench_gemv: single-GPU contexts only");
+    if (c->world > 1 || c->comm || c->f32) return fail("lmrs_bench_gemv: single-GPU contexts with quantised weights only");
     HIP_OK(hipSetDevice(c->device));
     const lmrs_args& a = c->args;
     const int nl = (int)a.n_layers, n_launch = 4 * nl + 1;
@@ -1336,7 +1373,7 @@ extern "C" int lmrs_debug_kv(lmrs_ctx* c, int which, uint32_t layer, uint32_t po
 extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, double* algo_bytes) {
     if (!c) return fail("ctx is NULL");
     const lmrs_args& a = c->args;
-    const double bpe = c->q4 ? 0.5 : 1.0, dim = a.dim, att = c->att_dim, kv = c->kv_dim, hid = a.hidden_dim, V = a.vocab_size, L = a.n_layers;
+    const double bpe = c->f32 ? 4.0 - 4.0 / 128.0 : (c->q4 ? 0.5 : 1.0), dim = a.dim, att = c->att_dim, kv = c->kv_dim, hid = a.hidden_dim, V = a.vocab_size, L = a.n_layers;   // (f32: 4 bytes, no scales)
     const double n_norm = a.model_type == LMRS_GEMMA ? 4 : 2;
     // weights + scales once, norm weights, KV read/write at this position
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +

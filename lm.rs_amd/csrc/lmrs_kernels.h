@@ -83,6 +83,9 @@ int launch_event_pool_used();                                     // launches se
 bool next_launch_events(hipEvent_t* a, hipEvent_t* b);            // for launches made outside lmrs_kernels.hip
 int gemv_grid(const GemvArgs& a, int pro, int epi);      // number of workgroups launch_gemv uses
 bool gemv_is_static(const GemvArgs& a, int pro, int epi); // a compile-time-shape kernel exists for this launch
+// unquantised models (q_type None): a.wq = o rows of n f32, a.xin = n f32; pro PRO_QUANT (as is) / PRO_RMS_QUANT (rmsnorm first); lmrs_f32.inc
+hipError_t launch_gemv_f32(const GemvArgs& a, int pro, int epi, hipStream_t s);
+int gemv_f32_grid(const GemvArgs& a, int epi);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 // long contexts: scores by (head, 256-key chunk), softmax + V by (head, quarter of the dims); S: attention_split_scratch_floats(..)
 size_t attention_split_scratch_floats(int n_heads, int seq_len);

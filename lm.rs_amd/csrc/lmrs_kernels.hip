@@ -1331,7 +1331,8 @@ hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks,
 // Embedding row (transformer.rs:324-332; quantization.rs:25-42) — dequantised on the fly, which is
 // bit-identical to reading the reference's load-time f32 copy of the table.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dequant_elem(const void* q, const float* s, int q4, size_t idx) {
+__device__ __forceinline__ float dequant_elem(const void* q, const float* s, int q4, size_t idx) {     // q4: 0 Q8_0, 1 Q4_0, 2 f32 table (q_type None)
+    if (q4 == 2) return reinterpret_cast<const float*>(q)[idx];
     if (!q4) return (float)reinterpret_cast<const int8_t*>(q)[idx] * s[idx / kGS];
     const int8_t v = reinterpret_cast<const int8_t*>(q)[idx >> 1];
     const int nib = (idx & 1) ? ((v >> 4) & 0x0F) - 8 : (v & 0x0F) - 8;
@@ -1616,6 +1617,7 @@ hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#include "lmrs_f32.inc"
 #include "lmrs_prefill.inc"
 #include "lmrs_vision.inc"
 #include "lmrs_fused.inc"

@@ -152,7 +152,7 @@ def test_matmul_q4(L, n, o):
 
 
 # ------------------------------------------------------------------ whole path, golden fixtures
-GOLDEN = ["tiny_llama_q8", "tiny_llama_q4", "tiny_phi_q8", "tiny_gemma_q8", "tiny_gemma_q4"]
+GOLDEN = ["tiny_llama_q8", "tiny_llama_q4", "tiny_phi_q8", "tiny_gemma_q8", "tiny_gemma_q4", "tiny_llama_f32"]
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -163,7 +163,7 @@ def test_golden_fixture_forward(L, golden_dir, name):
     m = L.Transformer(img); orc = O.Oracle(img)
     assert m.bytes_consumed == orc.bytes_consumed == img.size
     cfg_seed = {"tiny_llama_q8": ("tiny-llama", 7), "tiny_llama_q4": ("tiny-llama", 7), "tiny_phi_q8": ("tiny-phi", 9),
-                "tiny_gemma_q8": ("tiny-gemma", 8), "tiny_gemma_q4": ("tiny-gemma", 8)}[name]
+                "tiny_gemma_q8": ("tiny-gemma", 8), "tiny_gemma_q4": ("tiny-gemma", 8), "tiny_llama_f32": ("tiny-llama", 7)}[name]
     prompt = S.prompt_tokens(*cfg_seed[:1], 5, cfg_seed[1])
     seq = list(prompt) + list(toks_gold[:-1])
     lg = None
@@ -278,6 +278,30 @@ def test_generate_greedy_with_a_long_prompt(L, cfg, n_prompt):
     orc = O.Oracle(img); orc.generate_greedy(prompt, 20)
     pos = n_prompt + 19
     assert_bit_equal(m.forward(int(got[-1]), pos), orc.forward(int(ref[-1]), pos), "decode after prompt + 20 tokens")
+
+
+@pytest.mark.parametrize("cfg", ["mini-llama", "mini-gemma", "mini-phi", "mini-llama8b"])
+def test_unquantised_models_logits_bit_exact(L, cfg):
+    """q_type None (f32 weights, the reference's `matmul`, functional.rs:142-171: chunk sums through wide's tree, added to the row in
+    chunk order): logits bit-equal at every step at the real head geometries, Gemma's separate norm + add launches, GELU and soft-cap,
+    Phi's lm_head; get_embeddings / fill_kv_cache (token by token) / greedy generation on top."""
+    img = S.build_image(cfg, S.Q_NONE, seed=17)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    assert m.bytes_consumed == orc.bytes_consumed == img.size
+    prompt = S.prompt_tokens(cfg, 4, 17)
+    tok = None
+    for pos in range(8):
+        t = int(prompt[pos]) if pos < len(prompt) else tok
+        lo = orc.forward(t, pos)
+        assert_bit_equal(m.forward(t, pos), lo, f"{cfg} f32 logits at pos {pos}")
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+    e_dev = m.get_embeddings(prompt); e_ref = orc.get_embeddings(prompt)
+    assert_bit_equal(e_dev, e_ref, "get_embeddings (f32 table)")
+    a = e_dev.copy(); b = e_ref.copy()
+    assert m.fill_kv_cache(a, 8) == orc.fill_kv_cache(b, 8) == 12
+    assert_bit_equal(a, b, "fill_kv_cache (f32)")
+    m2 = L.Transformer(img); o2 = O.Oracle(img)
+    assert (m2.generate_greedy(prompt, 12) == o2.generate_greedy(prompt, 12)).all()
 
 
 @pytest.mark.parametrize("cfg,q", [("mini-phi", S.Q8_0), ("mini-gemma", S.Q4_0)])

@@ -459,6 +459,7 @@ int enqueue_exchange(lmrs_ctx* c, const ExchangeDesc& e) {
     if (c->p2p) {
         if (!c->p2p_ready) return fail("peer-to-peer transport: peers not connected yet (lmrs_p2p_connect)");
         if (c->ex_slot >= kMaxExchangeSlots) return fail("too many exchanges in one step");
+        if (e.stride % 16) return fail("peer-to-peer exchange: blocks must be 16-byte multiples");     // the push kernel copies 16 bytes per lane
         ExchangeArgs x{};
         const size_t off = (size_t)(e.buf - c->xarena) + (size_t)c->rank * e.stride;
         x.local = c->xarena + off; x.bytes = (int)((e.bytes + 15) & ~(size_t)15); x.rank = c->rank; x.world = c->world; x.slot = c->ex_slot;

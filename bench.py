@@ -144,6 +144,12 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def all_ranks_ok(ok):
+        import torch
+        flag = torch.tensor([1 if ok else 0], device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
     import lmrs_amd
     from tools import synth_lmrs as S
     lmrs_amd.build()                       # (re)compile liblmrs_hip.so if it is missing or older than its sources (a fresh clone has none)
@@ -178,9 +184,7 @@ def main():
             except Exception as e:                      # noqa: BLE001 - any failure means: fall back, together
                 print(f"[rank {rank}] peer-to-peer transport unavailable: {e}", file=sys.stderr)
                 ok = 0
-            import torch
-            flag = torch.tensor([ok], device="cpu" if dist.get_backend() == "gloo" else "cuda"); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
+            if all_ranks_ok(ok == 1):
                 transport = "p2p"
             else:
                 if model is not None:
@@ -193,15 +197,35 @@ def main():
     else:
         model = lmrs_amd.Transformer(img, device=local_rank)
 
-    # ---- warm-up: the W prompt tokens (token by token, as the reference feeds prompts), untimed
-    first = model.generate_greedy(prompt, 1)
-    device_sync(); barrier()
-    # ---- timed: exactly K decode steps at positions W .. W+K-1
-    t1 = time.perf_counter()
-    toks, dev_sec = model.generate_greedy(first, K, start_pos=W, timing=True)
-    device_sync(); barrier()
-    t2 = time.perf_counter()
-    elapsed = max_over_ranks(dist, t2 - t1, ("cpu" if dist.get_backend() == "gloo" else "cuda") if dist is not None else None)
+    def timed_run(model):
+        # ---- warm-up: the W prompt tokens (token by token, as the reference feeds prompts), untimed
+        first = model.generate_greedy(prompt, 1)
+        device_sync(); barrier()
+        # ---- timed: exactly K decode steps at positions W .. W+K-1
+        t1 = time.perf_counter()
+        toks, dev_sec = model.generate_greedy(first, K, start_pos=W, timing=True)
+        device_sync(); barrier()
+        t2 = time.perf_counter()
+        return first, toks, dev_sec, t2 - t1
+
+    if transport == "p2p":
+        # a peer-to-peer exchange that times out mid-run (bounded wait, sticky error) must not cost the job its result: every rank
+        # reports, and if any of them failed all of them redo the run over RCCL
+        res = None
+        try:
+            res = timed_run(model)
+        except Exception as e:                          # noqa: BLE001
+            print(f"[rank {rank}] peer-to-peer run failed: {e}", file=sys.stderr)
+        if not all_ranks_ok(res is not None):
+            model.close()
+            uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
+            model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
+            transport = "rccl (peer-to-peer run failed)"
+            res = timed_run(model)
+    else:
+        res = timed_run(model)
+    first, toks, dev_sec, wall = res
+    elapsed = max_over_ranks(dist, wall, ("cpu" if dist.get_backend() == "gloo" else "cuda") if dist is not None else None)
     gen = np.concatenate([first, toks])[: K + 1]          # token ids produced after positions W-1 .. W+K-1
     shard_steps = None
     if sharded:

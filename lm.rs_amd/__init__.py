@@ -47,9 +47,19 @@ def build(force: bool = False) -> str:
     """Compile liblmrs_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", ".inc"))]
     srcs.append(os.path.join(_HERE, "..", "include", "lmrs_hip.h"))
-    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if stale:
-        subprocess.run(["make", "-s", "-j4", "-C", CSRC], check=True)
+    def stale():
+        return not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale():
+        # one builder at a time: the ranks of a multi-GPU launch all come through here (bench.py), and two `make`s writing the same
+        # objects corrupt them; whoever waited finds the library fresh and skips the build
+        import fcntl
+        with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or stale():
+                    subprocess.run(["make", "-s", "-j4", "-C", CSRC], check=True)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -138,7 +138,7 @@ void rope_terms(const lmrs_args& a, uint32_t p, uint32_t j, float* fcr, float* f
         }
     }
     if (a.model_type == LMRS_PHI) {                            // LongRoPE short factors + long magnitude
-        freq = freq * (float)(1.0 / short_factor[j % 48]);
+        freq = freq * (float)(1.0 / short_factor[j]);          // j < 48: checked at create
         const float scale = 131072.0f / 4096.0f;
         scaling_factor = sqrtf(1.0f + logf(scale) / logf(4096.0f));
     }
@@ -255,13 +255,25 @@ int enqueue_finish_residual(lmrs_ctx* c) {
     return 0;
 }
 
+// classifier rows this context computes: its slice of the vocabulary, cut at the last multiple of 4 of the whole vocabulary
+static int cls_rows(const lmrs_ctx* c) {
+    if (c->q4) return c->voc_l;                          // matmul_q4 walks every row (par_iter_mut, functional.rs:226): no unwritten tail
+    const int written = (int)(c->args.vocab_size & ~3u) - c->v0;
+    return written < c->voc_l ? (written > 0 ? written : 0) : c->voc_l;
+}
+
+// first of the never-written logits (they hold 0.0), or 0 when the vocabulary is a multiple of 4
+static int unwritten_tail(const lmrs_ctx* c) { return !c->q4 && c->args.vocab_size % 4 ? (int)(c->args.vocab_size & ~3u) : 0; }
+
 GemvArgs cls_args(lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     GemvArgs g{};
     g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = a.model_type == LMRS_GEMMA; g.st = c->st;
     const size_t row_bytes = c->f32 ? (size_t)a.dim * 4 : (c->q4 ? a.dim / 2 : a.dim);
     g.wq = static_cast<const char*>(c->cls_q) + (size_t)c->v0 * row_bytes; g.ws = c->f32 ? nullptr : c->cls_s + (size_t)c->v0 * (a.dim / 128);
-    g.n = a.dim; g.o = c->voc_l; g.xin = c->x; g.rms_w = c->rms_final; g.row_offset = c->v0;
+    // matmul_q8 / matmul (not matmul_q4) hand out the output rows four at a time (par_chunks_exact_mut(4), functional.rs:148,179): the last
+    // vocab_size % 4 logits are never written - they keep the 0.0 the buffer was created with, and argmax sees them as 0.0
+    g.n = a.dim; g.o = cls_rows(c); g.xin = c->x; g.rms_w = c->rms_final; g.row_offset = c->v0;
     g.out = c->logits + c->v0;
     if (c->world > 1 || c->comm) {          // sharded: this shard's [values | indices] block of the gathered partials
         g.part_val = c->part + (size_t)c->rank * 2 * c->cls_grid;
@@ -293,7 +305,7 @@ int enqueue_step(lmrs_ctx* c) {
     else HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
     set_launch_tag(6);
     ArgmaxArgs m{};
-    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.flags = c->flags; m.n_flag_words = c->n_flag_words;
+    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tail_row = unwritten_tail(c); m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.flags = c->flags; m.n_flag_words = c->n_flag_words;
     m.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
@@ -417,7 +429,7 @@ int run_segment(lmrs_ctx* c, int seg) {
     ArgmaxArgs m{};
     m.part_val = c->part; m.part_idx = reinterpret_cast<const int*>(c->part) + c->cls_grid; m.n_part = c->cls_grid;
     m.n_groups = c->world; m.group_stride = 2 * c->cls_grid;
-    m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c);
+    m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.tail_row = unwritten_tail(c);
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
 }
@@ -705,6 +717,8 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     const size_t dim = a.dim, att = (size_t)a.n_heads * a.head_size, kv = (size_t)a.n_kv_heads * a.head_size, hid = a.hidden_dim, V = a.vocab_size;
     if (dim % 128 || att % 128 || hid % 128) return fail("dim, n_heads*head_size and hidden_dim must be multiples of 128");
     if (dim > 10240 || att > 10240 || hid > 16384) return fail("vector lengths above 10240 (dim, attention) / 16384 (hidden) are not supported");
+    if (a.model_type == LMRS_PHI && a.head_size > 96)
+        return fail("Phi: head_size above 96 indexes past the 48 LongRoPE short factors (transformer.rs:473-475: the reference panics)");
     if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128 && a.head_size != 256) return fail("head_size must be 64, 96, 128 or 256 (the model families lm.rs supports)");
     int ndev = 0;
     hipError_t de = hipGetDeviceCount(&ndev);
@@ -716,6 +730,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     const size_t W = (size_t)world;
     if (world > 1 && (a.n_kv_heads % W || dim % W || hid % W || V % W))
         return fail("world must divide n_kv_heads, dim, hidden_dim and vocab_size");
+    if (a.vocab_size / (uint32_t)world < 4) return fail("vocab_size / world must be at least 4");
     const size_t hs = a.head_size;
     // wo and w2 (the projections back to the residual stream) are REPLICATED by default: every shard computes all dim rows
     // from the gathered att_out / h, so the residual needs no gather of its own - two all-gathers per layer instead of four,
@@ -895,7 +910,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         // step has a static kernel that can do it (otherwise: the separate addnorm launches)
         GemvArgs q{}; q.q4 = c->q4; q.n = a.dim; q.o = c->att_dim + 2 * c->kv_dim;
         GemvArgs f = q; f.o = 2 * a.hidden_dim;
-        GemvArgs k = q; k.o = c->voc_l; k.softcap_rows = (int)a.dim;
+        GemvArgs k = q; k.o = cls_rows(c); k.softcap_rows = (int)a.dim;
         c->gemma_fused = gemv_is_static(q, PRO_ADD_RMS_QUANT, EPI_QKV) && gemv_is_static(f, PRO_ADD_RMS_QUANT, EPI_GELU) &&
                          gemv_is_static(k, PRO_ADD_RMS_QUANT, EPI_CLS);
     }
@@ -1504,7 +1519,7 @@ extern "C" int lmrs_op_classifier_argmax(int device, const float* x, const float
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, nullptr));
     ArgmaxArgs m{};
     m.part_val = g.part_val; m.part_idx = g.part_idx; m.n_part = grid; m.n_groups = 1; m.logits = g.out; m.tokens = static_cast<uint32_t*>(dtok); m.st = static_cast<DevState*>(dst);
-    m.emb.dim = 0;                                      // no embedding row to prepare
+    m.emb.dim = 0; m.tail_row = 0;                      // no embedding row to prepare; o % 4 == 0
     HIP_OK(launch_argmax_final(m, nullptr));
     uint32_t tk[2];
     HIP_OK(hipMemcpy(tk, dtok, 8, hipMemcpyDeviceToHost));

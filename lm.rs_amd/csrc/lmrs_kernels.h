@@ -68,6 +68,7 @@ struct ArgmaxArgs {
     const float* part_val; const int* part_idx; int n_part;
     int n_groups, group_stride;   // row-sharded classifier: n_groups shards of partials, group_stride entries apart (1 shard: 1, 0)
     const float* logits;
+    int tail_row;            // > 0: logits[tail_row ..] are never written by the classifier (vocab % 4 rows, functional.rs:183) and hold 0.0
     uint32_t* tokens; DevState* st;
     EmbedArgs emb;           // the winner's (or the next prompt token's) embedding row is written to emb.x
     unsigned* flags; int n_flag_words;   // in-launch arrival counters of the fused kernels: re-zeroed here, at the end of the step

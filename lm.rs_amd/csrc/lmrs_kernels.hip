@@ -1374,6 +1374,7 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
     LMRS_STAMP(0);
     if (a.dbg && threadIdx.x == 0) a.dbg[1] = clock64();          // shader-clock cycles, to derive the running clock
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
+    if (threadIdx.x == 0 && a.tail_row > 0) { best = 0.0f; best_i = a.tail_row; }   // the unwritten last rows: 0.0, the first of them wins their tie
     int nan0 = 0;                                                  // index -1: the logit at index 0 is NaN (cls_flag_nan_at_zero)
     // partials: n_groups shards x n_part entries; shard g holds [values | indices] at part_val + g * group_stride
     for (int i = threadIdx.x; i < a.n_part * a.n_groups; i += kBlock) {

@@ -97,6 +97,21 @@ def matmul_q(xq, xs, wq, ws, n, o, gs, q4):
     return out
 
 
+def matmul_f32(x, w, n, o):
+    """matmul (functional.rs:142-171), one token: per row, chunks of 8 in order, xout += (x_vec * w_vec).reduce_add() with wide's AVX
+    tree ((p0+p4)+(p2+p6)) + ((p1+p5)+(p3+p7)); rows in groups of 4 (par_chunks_exact_mut(4): a shorter last group is never written)."""
+    nc = n // 8
+    P = (w.reshape(o, n)[:, :nc * 8].reshape(o, nc, 8) * x[:nc * 8].reshape(1, nc, 8)).astype(F)
+    q0 = (P[..., 0] + P[..., 4]).astype(F); q1 = (P[..., 1] + P[..., 5]).astype(F)
+    q2 = (P[..., 2] + P[..., 6]).astype(F); q3 = (P[..., 3] + P[..., 7]).astype(F)
+    S = ((q0 + q2).astype(F) + (q1 + q3).astype(F)).astype(F)                    # [o, nc] chunk sums
+    out = np.zeros(o, F)
+    for j in range(nc):
+        out = (out + S[:, j]).astype(F)
+    out[(o // 4) * 4:] = 0
+    return out
+
+
 PHI_SHORT = [1.08, 1.1, 1.1300000000000001, 1.2800000000000002, 1.3100000000000003, 1.4500000000000004, 1.4500000000000004, 1.9500000000000008,
              2.030000000000001, 2.4299999999999926, 2.5699999999999896, 2.9499999999999815, 3.729999999999965, 3.869999999999962, 4.189999999999955,
              4.43999999999995, 4.6399999999999455, 4.979999999999938, 5.159999999999934, 5.279999999999932, 5.759999999999922, 5.889999999999919,
@@ -123,6 +138,8 @@ class NumpyModel:
 
         def quant(n_t, each):
             out = []
+            if self.q_type == 0:                                   # q_type None: plain f32 tensors, no scales (init_param, transformer.rs:16-22)
+                return [(f32(each), None) for _ in range(n_t)]
             for _ in range(n_t):
                 qb = each // 2 if self.q_type == 2 else each
                 q = img[off[0]:off[0] + qb]; off[0] += qb
@@ -144,13 +161,19 @@ class NumpyModel:
         self.kc = np.zeros((L, self.seq_len, kv), F); self.vc = np.zeros((L, self.seq_len, kv), F)
 
     def _q(self, x):
+        if self.q_type == 0:
+            return x, None                                         # unquantised: the activation goes into matmul as it is
         return quantize_q4(x, self.gs) if self.q_type == 2 else quantize_q8(x, self.gs)
 
     def _mm(self, xq, xs, w, n, o):
+        if self.q_type == 0:
+            return matmul_f32(xq, w[0], n, o)
         return matmul_q(xq, xs, w[0], w[1], n, o, self.gs, self.q_type == 2)
 
     def embed(self, token):
         q, s = self.emb
+        if self.q_type == 0:
+            return q[token * self.dim:(token + 1) * self.dim].copy()
         if self.q_type == 2:
             vals = unpack_q4(q[token * self.dim // 2:(token + 1) * self.dim // 2].reshape(1, -1))[0].astype(F)
         else:

@@ -175,7 +175,7 @@ def test_golden_fixture_forward(L, golden_dir, name):
     assert (m2.generate_greedy(prompt, len(toks_gold)) == toks_gold).all()
 
 
-@pytest.mark.parametrize("cfg", ["mini-llama", "mini-llama3b", "mini-phi", "mini-llama8b"])
+@pytest.mark.parametrize("cfg", ["mini-llama", "mini-llama3b", "mini-phi", "mini-llama8b", "mini-llama-v4102"])
 def test_mini_models_logits_bit_exact(L, cfg):
     img = S.build_image(cfg, S.Q8_0, seed=11)
     m = L.Transformer(img); orc = O.Oracle(img)
@@ -206,6 +206,33 @@ def test_mini_q4_and_gemma_logits_bit_exact(L, cfg, q):
         t = int(prompt[pos]) if pos < len(prompt) else tok
         lo = orc.forward(t, pos)
         assert_bit_equal(m.forward(t, pos), lo, f"{cfg} q{q} logits at pos {pos}")
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+
+
+@pytest.mark.parametrize("i", range(18))
+def test_random_geometries_single_token_and_batched(L, i):
+    """Geometries no kernel was tuned or instantiated for (random family, heads, kv heads, head size, hidden, depth and a vocabulary
+    that is not a multiple of 4), in each weight format: single-token steps, then a batched prefill and decode steps on its cache."""
+    rng = np.random.default_rng(2000 + i)
+    cfg = S.random_cfg(rng, i, max_pos=128)
+    q = [S.Q8_0, S.Q4_0, S.Q_NONE][i % 3]
+    img = S.build_image(cfg, q, seed=70 + i, threads=1)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    tok = int(rng.integers(0, cfg.vocab_size))
+    for pos in range(5):
+        lo = orc.forward(tok, pos)
+        assert_bit_equal(m.forward(tok, pos), lo, f"{cfg} q{q} logits at pos {pos}")
+        nxt = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+        assert m.forward_argmax(tok, pos) == nxt
+        tok = nxt
+    n_tok = int(rng.integers(18, 90))
+    toks = S.prompt_tokens(cfg, n_tok, 70 + i)
+    a = m.get_embeddings(toks); b = orc.get_embeddings(toks)
+    assert m.fill_kv_cache(a, 5) == orc.fill_kv_cache(b, 5) == 5 + n_tok
+    assert_bit_equal(a, b, f"{cfg} q{q}: residual stream after {n_tok} batched tokens")
+    for pos in range(5 + n_tok, 5 + n_tok + 2):
+        lo = orc.forward(tok, pos)
+        assert_bit_equal(m.forward(tok, pos), lo, f"{cfg} q{q}: decode at {pos} on the prefilled cache")
         tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
@@ -464,7 +491,8 @@ def test_split_attention_for_long_contexts(L, monkeypatch, cfg, q, n_steps, spli
     ("mini-llama", S.Q8_0, 2, "int8"), ("mini-llama", S.Q8_0, 8, "int8"), ("mini-llama3b", S.Q8_0, 4, "int8"), ("mini-phi", S.Q8_0, 8, "int8"),
     ("mini-llama", S.Q8_0, 4, "f32"), ("mini-llama", S.Q8_0, 4, "split"), ("mini-llama3b", S.Q8_0, 8, "split"),
     ("mini-gemma", S.Q8_0, 2, "int8"), ("mini-gemma", S.Q8_0, 4, "split"), ("mini-gemma", S.Q4_0, 4, "int8"), ("mini-llama", S.Q4_0, 4, "int8"),
-    ("mini-llama", S.Q8_0, 2, "p2p"), ("mini-llama3b", S.Q8_0, 2, "p2p"), ("mini-gemma", S.Q8_0, 2, "p2p-split")])
+    ("mini-llama", S.Q8_0, 2, "p2p"), ("mini-llama3b", S.Q8_0, 2, "p2p"), ("mini-gemma", S.Q8_0, 2, "p2p-split"),
+    ("mini-llama-v4102", S.Q8_0, 2, "int8")])
 def test_row_sharding_is_bit_identical(L, monkeypatch, cfg, q, world, mode):
     """`world` logical shards on ONE device - same kernels, same partition as the multi-GPU path: every logit must equal the unsharded
     CPU path bit for bit.  int8: att_out / h travel quantised by their producers (Q8_0; Q4_0 models fall back to f32 slices);
@@ -601,6 +629,12 @@ def test_errors(L):
         m.forward(0, m.args.seq_len)
     with pytest.raises(L.LmrsError):
         m.generate_greedy(np.zeros(0, np.uint32), 4)
+    # Phi with a head size above 96: the reference indexes past its 48 LongRoPE factors and panics (transformer.rs:473-475)
+    phi128 = S.build_image(S.ModelCfg("phi-128", 128, 128, 1, 2, 128, 2, 256, 32, 1e-5, 10000.0, S.PHI), S.Q8_0, seed=3, threads=1)
+    with pytest.raises(L.LmrsError, match="LongRoPE"):
+        L.Transformer(phi128)
+    with pytest.raises(Exception, match="LongRoPE"):
+        O.Oracle(phi128)
 
 
 # ------------------------------------------------------------------ CLIP image tower (BASELINE configs[4])

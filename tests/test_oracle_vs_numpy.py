@@ -10,7 +10,7 @@ import oracle_lib as O
 from tools import synth_lmrs as S
 
 CASES = [("tiny_llama_q8", "tiny-llama", 7), ("tiny_llama_q4", "tiny-llama", 7), ("tiny_gemma_q8", "tiny-gemma", 8),
-         ("tiny_gemma_q4", "tiny-gemma", 8), ("tiny_phi_q8", "tiny-phi", 9)]
+         ("tiny_gemma_q4", "tiny-gemma", 8), ("tiny_phi_q8", "tiny-phi", 9), ("tiny_llama_f32", "tiny-llama", 7)]
 
 
 @pytest.mark.parametrize("name,cfg,seed", CASES)
@@ -112,3 +112,20 @@ def test_fill_kv_cache_oracle_matches_numpy_transcription(golden_dir, name, cfg,
     assert (flat.view(np.uint32) == b.reshape(-1).view(np.uint32)).all(), np.flatnonzero(flat != b.reshape(-1))[:5]
     lo = orc.forward(3, pos0 + n_tok).copy(); ln = ref.forward(3, pos0 + n_tok)
     assert (lo.view(np.uint32) == ln.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_oracle_matches_numpy_on_random_geometries(i):
+    """The two transcriptions of the forward pass on geometries neither was written against: random family / heads / kv heads /
+    head size / hidden / vocabulary / depth, all three weight formats (Q8_0, Q4_0, f32)."""
+    rng = np.random.default_rng(1000 + i)
+    cfg = S.random_cfg(rng, i)
+    q = [S.Q8_0, S.Q4_0, S.Q_NONE][i % 3]
+    img = S.build_image(cfg, q, seed=50 + i, threads=1)
+    orc = O.Oracle(img); ref = NR.NumpyModel(img)
+    assert ref.end == orc.bytes_consumed == img.size
+    tok = int(rng.integers(0, cfg.vocab_size))
+    for pos in range(4):
+        lo = orc.forward(tok, pos).copy(); ln = ref.forward(tok, pos)
+        assert (lo.view(np.uint32) == ln.view(np.uint32)).all(), f"{cfg} q{q} pos {pos}: {np.flatnonzero(lo != ln)[:5]}"
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))

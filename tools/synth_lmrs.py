@@ -61,6 +61,8 @@ CONFIGS = {
     "tiny-phi": ModelCfg("tiny-phi", 128, 256, 2, 4, 96, 4, 256, 64, 1e-5, 10000.0, PHI),
     # mid-size: real head geometry of the 1B model, few layers, small vocab (fast oracle runs)
     "mini-llama": ModelCfg("mini-llama", 2048, 8192, 2, 32, 64, 8, 4096, 256, 1e-5, 500000.0, LLAMA),
+    # a vocabulary that is not a multiple of 4: its last two logits are never written by the reference (functional.rs:183)
+    "mini-llama-v4102": ModelCfg("mini-llama-v4102", 2048, 8192, 2, 32, 64, 8, 4102, 256, 1e-5, 500000.0, LLAMA),
     "mini-llama-long": ModelCfg("mini-llama-long", 2048, 8192, 2, 32, 64, 8, 4096, 2048, 1e-5, 500000.0, LLAMA),
     "mini-phi-long": ModelCfg("mini-phi-long", 3072, 8192, 2, 32, 96, 32, 4096, 1024, 1e-5, 10000.0, PHI),
     "mini-llama3b": ModelCfg("mini-llama3b", 3072, 8192, 2, 24, 128, 8, 4096, 256, 1e-5, 500000.0, LLAMA),
@@ -229,6 +231,25 @@ def build_image(cfg: ModelCfg | str, q_type: int = Q8_0, seed: int = 1234, gs: i
         for t in tasks:
             run(t)
     return img
+
+
+def random_cfg(rng, i: int, max_pos: int = 32) -> ModelCfg:
+    """A small random geometry of one of the three families: heads / kv heads / head size / hidden / vocabulary / depth all drawn
+    (within what a real LMRS file can hold: every quantised matmul input a multiple of the group size 128)."""
+    mt = int(rng.integers(0, 3))
+    # Phi: the LongRoPE table has 48 entries (transformer.rs:473): head sizes up to 96
+    hs = int(rng.choice([[64, 128, 256], [64, 96, 128], [64, 96]][mt]))
+    while True:                                                            # wo's input (n_heads * head_size) is quantised in groups of 128
+        n_kv = int(rng.choice([1, 2]))
+        n_heads = n_kv * int(rng.choice([1, 2, 3, 4]))
+        if n_heads * hs % 128 == 0:
+            break
+    dim = int(rng.choice([128, 256]))
+    hidden = int(rng.choice([128, 256, 384]))
+    # >= dim: Gemma's soft-cap loop indexes logits[0..dim) (transformer.rs:375); also vocabularies that are not a multiple of 4 (tail rows, Q6)
+    vocab = dim + int(rng.integers(1, 40)) * 4 + int(rng.choice([0, 1, 3]))
+    return ModelCfg(f"rand{i}", dim, hidden, int(rng.integers(1, 4)), n_heads, hs, n_kv, vocab, max_pos, [1e-6, 1e-5][mt != 0],
+                    [10000.0, 500000.0, 10000.0][mt], mt)
 
 
 def prompt_tokens(cfg: ModelCfg | str, n: int = 16, seed: int = 1234) -> np.ndarray:

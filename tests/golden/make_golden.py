@@ -66,20 +66,23 @@ def mm_vision_cfg():
     return V.VisionCfg(dim=128, hidden_dim=512, n_layers=2, n_heads=2, head_size=64)
 
 
-def mm_expected_image():
+def mm_expected_image(q_type=S.Q8_0):
     """What tools/synth_lmrs.py + tools/synth_vision.py write for the multimodal fixture: text image with the multimodal flag set,
     then the vision section, then the processor section."""
     from tools import synth_vision as V
     cfg = S.CONFIGS[MM_TEXT_CFG]
-    text = S.build_image(cfg, S.Q8_0, MM_SEED).copy()
+    text = S.build_image(cfg, q_type, MM_SEED).copy()
     text[54] = 1                                                      # header: multimodal flag (export.py:80)
     vcfg = mm_vision_cfg()
-    vis = V.build_vision_section(vcfg, MM_VSEED)
-    proc = V.build_processor_section(4 * vcfg.dim, cfg.dim, MM_PSEED)
+    vis = V.build_vision_section(vcfg, MM_VSEED, q_type=q_type)
+    proc = V.build_processor_section(4 * vcfg.dim, cfg.dim, MM_PSEED, q_type=q_type)
     return text, vis, proc
 
 
-def export_multimodal():
+MM_VARIANTS = {S.Q8_0: "tiny_phi_vision_q8", S.Q4_0: "tiny_phi_vision_q4", S.Q_NONE: "tiny_phi_vision_f32"}
+
+
+def export_multimodal(q_type=S.Q8_0):
     """The reference exporter on a tiny Phi + CLIP + projector checkpoint (--vision-config): pins the layout of the vision and
     processor sections (export.py:126-170) that tools/synth_vision.py restates.  Only sizes and the SHA-256 are committed."""
     import hashlib
@@ -89,7 +92,8 @@ def export_multimodal():
     cfg = S.CONFIGS[MM_TEXT_CFG]
     vcfg = mm_vision_cfg()
     assert vcfg.hidden_dim == 4 * vcfg.dim
-    base = os.path.join(HERE, MM_NAME)
+    name = MM_VARIANTS[q_type]
+    base = os.path.join(HERE, name)
     with tempfile.TemporaryDirectory() as td:
         sd = dict(S.hf_state_dict(cfg, MM_SEED))
         sd.update(V.hf_vision_state_dict(vcfg, 4 * vcfg.dim, cfg.dim, MM_VSEED, MM_PSEED))
@@ -101,12 +105,13 @@ def export_multimodal():
         out = os.path.join(td, "mm")
         subprocess.run([sys.executable, os.path.join(REF, "export.py"), "--files", os.path.join(td, "model.safetensors"), "--config",
                         os.path.join(td, "config.json"), "--vision-config", os.path.join(td, "vision.json"), "--save-path", out,
-                        "--type", "PHI", "--quantize", "--quantize-type", "1"], check=True, cwd=REF, stdout=subprocess.DEVNULL)
+                        "--type", "PHI"] + (["--quantize", "--quantize-type", str(q_type)] if q_type != S.Q_NONE else []),
+                       check=True, cwd=REF, stdout=subprocess.DEVNULL)
         ref = np.fromfile(out + ".lmrs", np.uint8)
-    text, vis, proc = mm_expected_image()
+    text, vis, proc = mm_expected_image(q_type)
     mine = np.concatenate([text, vis, proc])
     same = ref.size == mine.size and bool((ref == mine).all())
-    print(f"{MM_NAME}: export.py wrote {ref.size} bytes (text {text.size} + vision {vis.size} + processor {proc.size}); synth writers identical: {same}")
+    print(f"{name}: export.py wrote {ref.size} bytes (text {text.size} + vision {vis.size} + processor {proc.size}); synth writers identical: {same}")
     if not same:
         n = min(ref.size, mine.size); d = np.flatnonzero(ref[:n] != mine[:n])
         print("   first difference at byte", int(d[0]) if d.size else n)
@@ -117,7 +122,8 @@ def export_multimodal():
 
 
 def main():
-    export_multimodal()
+    for q in MM_VARIANTS:
+        export_multimodal(q)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
     for name, cfg_name, q_type, seed in FIXTURES:

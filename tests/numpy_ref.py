@@ -317,29 +317,36 @@ def gelu_tanh(h):
 
 def processor_forward(section, feats, w_crop, h_crop, rows=None):
     hidden, text = struct.unpack_from("II", section, 0)
+    qt = section[8]
     gs = struct.unpack_from("I", section, 9)[0]
     off = 128
     def take(dt, cnt):
         nonlocal off
         a = np.frombuffer(section, dt, cnt, off); off += a.nbytes
         return a
+    def take_w(cnt):
+        if qt == 0: return take(F, cnt), None
+        if qt == 2: return take(np.uint8, cnt // 2), take(F, cnt // gs)
+        return take(np.int8, cnt), take(F, cnt // gs)
     glb, sub = take(F, hidden), take(F, hidden)
-    p0, s0 = take(np.int8, text * hidden), take(F, text * hidden // gs)
-    p1, s1 = take(np.int8, text * text), take(F, text * text // gs)
+    p0, s0 = take_w(text * hidden)
+    p1, s1 = take_w(text * text)
     b0, b1 = take(F, text), take(F, text)
     emb = np.concatenate([hd_transform(feats[1:], h_crop, w_crop, sub), glb.reshape(1, -1), hd_transform(feats[:1], 1, 1, sub)])
     pick = range(emb.shape[0]) if rows is None else rows
     out = {}
+    def mm(x, w, ws, n, o):
+        if qt == 0: return matmul_f32(x, w, n, o)
+        q, sc = quantize_q4(x, gs) if qt == 2 else quantize_q8(x, gs)
+        return matmul_q(q, sc, w, ws, n, o, gs, qt == 2)
     for r in pick:
-        q, sc = quantize_q8(emb[r], gs)
-        h = (matmul_q(q, sc, p0, s0, hidden, text, gs, False) + b0).astype(F)
+        h = (mm(emb[r], p0, s0, hidden, text) + b0).astype(F)
         h = gelu_tanh(h)
-        q, sc = quantize_q8(h, gs)
-        out[r] = (matmul_q(q, sc, p1, s1, text, text, gs, False) + b1).astype(F)
+        out[r] = (mm(h, p1, s1, text, text) + b1).astype(F)
     return emb.shape[0], out
 
 
-# ------------------------------------------------------------------ CLIP tower (reference src/vision.rs:99-577), Q8_0
+# ------------------------------------------------------------------ CLIP tower (reference src/vision.rs:99-577): Q8_0, Q4_0 or f32 sections
 def _expf_arr(a):
     f = _libm.expf
     return np.array([f(float(v)) for v in a.reshape(-1)], F).reshape(a.shape)
@@ -375,13 +382,29 @@ def layernorm_rows(x, w, b, eps):
     return ((nrm * w[None, :]).astype(F) + b[None, :]).astype(F)
 
 
-def quant_matmul_rows(x, wq, ws, n, o, gs):
-    """quantize (quantization.rs:25-60) + matmul_q8 (functional.rs) for every row of x [T, n] -> [T, o]."""
+def quant_matmul_rows(x, wq, ws, n, o, gs, qt=1):
+    """The section's quantiser (quantization.rs:44-95) + matmul_q8 / matmul_q4, or the plain matmul (functional.rs:142-250), for
+    every row of x [T, n] -> [T, o].  qt: 1 Q8_0, 2 Q4_0 (packed nibbles on both sides), 0 unquantised f32."""
     T = x.shape[0]
+    if qt == 0:
+        w = wq.reshape(o, n)
+        out = np.zeros((T, o), F)
+        for j in range(n // 8):                                        # chunk sums through wide's tree, added to the row in order
+            pr = (x[:, None, j * 8:j * 8 + 8] * w[None, :, j * 8:j * 8 + 8]).astype(F)
+            out = (out + reduce_add8(np.moveaxis(pr, -1, 0))).astype(F)
+        return out
     G = n // gs
-    q = np.empty((T, n), np.int8); sc = np.empty((T, G), F)
-    for t in range(T):
-        q[t], sc[t] = quantize_q8(x[t], gs)
+    sc = np.empty((T, G), F)
+    if qt == 2:
+        q = np.empty((T, n), np.int32)
+        for t in range(T):
+            pk, sc[t] = quantize_q4(x[t], gs)
+            q[t] = unpack_q4(pk.reshape(1, n // 2))[0]
+        wq = unpack_q4(wq.reshape(o, n // 2))
+    else:
+        q = np.empty((T, n), np.int8)
+        for t in range(T):
+            q[t], sc[t] = quantize_q8(x[t], gs)
     Wf = wq.reshape(o, G, gs).astype(np.float64); Xf = q.reshape(T, G, gs).astype(np.float64)
     WS = ws.reshape(o, G)
     out = np.zeros((T, o), F)
@@ -398,6 +421,7 @@ def vision_forward(section, pixel_values):
     dim, hid, n_layers, n_heads, hs = struct.unpack_from("5I", section, 0)
     eps = struct.unpack_from("f", section, 20)[0]
     patch, image = struct.unpack_from("2I", section, 24)
+    qt = section[32]
     gs = struct.unpack_from("I", section, 33)[0]
     off = 128
     def take(dt, *shape):
@@ -407,7 +431,9 @@ def vision_forward(section, pixel_values):
     def take_q(o, n):
         qs, ss = [], []
         for _ in range(n_layers):
-            qs.append(take(np.int8, o, n)); ss.append(take(F, o * n // gs))
+            if qt == 0: qs.append(take(F, o, n)); ss.append(None)
+            elif qt == 2: qs.append(take(np.uint8, o, n // 2)); ss.append(take(F, o * n // gs))
+            else: qs.append(take(np.int8, o, n)); ss.append(take(F, o * n // gs))
         return qs, ss
     kd = 3 * patch * patch
     cls = take(F, dim); pe = take(F, dim, kd); pos = take(F, 577, dim)
@@ -436,9 +462,9 @@ def vision_forward(section, pixel_values):
         x = nrm.copy()
         e = layernorm_rows(nrm, ln1w[l], ln1b[l], eps)
         # the three projections share one quantisation of the row
-        q = ((quant_matmul_rows(e, wq[0][l], wq[1][l], dim, dim, gs) + wqb[l]).astype(F) / scale).astype(F)
-        k = (quant_matmul_rows(e, wk[0][l], wk[1][l], dim, dim, gs) + wkb[l]).astype(F)
-        v = (quant_matmul_rows(e, wv[0][l], wv[1][l], dim, dim, gs) + wvb[l]).astype(F)
+        q = ((quant_matmul_rows(e, wq[0][l], wq[1][l], dim, dim, gs, qt) + wqb[l]).astype(F) / scale).astype(F)
+        k = (quant_matmul_rows(e, wk[0][l], wk[1][l], dim, dim, gs, qt) + wkb[l]).astype(F)
+        v = (quant_matmul_rows(e, wv[0][l], wv[1][l], dim, dim, gs, qt) + wvb[l]).astype(F)
         ao = np.empty((T, dim), F)
         for h in range(n_heads):
             qh, kh, vh = q[:, h * hs:(h + 1) * hs], k[:, h * hs:(h + 1) * hs], v[:, h * hs:(h + 1) * hs]
@@ -453,13 +479,13 @@ def vision_forward(section, pixel_values):
             for r in range(nb2, T):
                 o_ = (o_ + (vh[r][None, :] * att[:, r:r + 1]).astype(F)).astype(F)
             ao[:, h * hs:(h + 1) * hs] = o_
-        e = (quant_matmul_rows(ao, wo[0][l], wo[1][l], dim, dim, gs) + wob[l]).astype(F)
+        e = (quant_matmul_rows(ao, wo[0][l], wo[1][l], dim, dim, gs, qt) + wob[l]).astype(F)
         e = (e + x).astype(F)
         x = e.copy()
         nrm = layernorm_rows(e, ln2w[l], ln2b[l], eps)
-        hdn = (quant_matmul_rows(nrm, w1[0][l], w1[1][l], dim, hid, gs) + w1b[l]).astype(F)
+        hdn = (quant_matmul_rows(nrm, w1[0][l], w1[1][l], dim, hid, gs, qt) + w1b[l]).astype(F)
         sg = (F(1.0) / (F(1.0) + _expf_arr(-(F(1.702) * hdn).astype(F))).astype(F)).astype(F)
         hdn = (hdn * sg).astype(F)
-        e = (quant_matmul_rows(hdn, w2[0][l], w2[1][l], hid, dim, gs) + w2b[l]).astype(F)
+        e = (quant_matmul_rows(hdn, w2[0][l], w2[1][l], hid, dim, gs, qt) + w2b[l]).astype(F)
         nrm = (e + x).astype(F)
     return end, nrm[1:]

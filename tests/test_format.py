@@ -65,7 +65,8 @@ def test_malformed_images_are_rejected():
         O.Oracle(img[:100])
 
 
-def test_multimodal_sections_match_the_reference_exporter(golden_dir):
+@pytest.mark.parametrize("q", [S.Q8_0, S.Q4_0, S.Q_NONE])
+def test_multimodal_sections_match_the_reference_exporter(golden_dir, q):
     """The vision and processor sections tools/synth_vision.py writes (the inputs of every image-path test) are, byte for byte,
     what the reference's export.py --vision-config wrote for the same tensors (tests/golden/make_golden.py recorded its size and
     SHA-256), and the CPU restatements of Transformer::new / VisionTransformer::new / PHI3VProcessor::new walk the file the way
@@ -75,8 +76,8 @@ def test_multimodal_sections_match_the_reference_exporter(golden_dir):
     import sys
     sys.path.insert(0, golden_dir)
     import make_golden as G
-    fx = json.load(open(os.path.join(golden_dir, "tiny_phi_vision_q8.json")))
-    text, vis, proc = G.mm_expected_image()
+    fx = json.load(open(os.path.join(golden_dir, G.MM_VARIANTS[q] + ".json")))
+    text, vis, proc = G.mm_expected_image(q)
     img = np.concatenate([text, vis, proc])
     assert (text.size, vis.size, proc.size, img.size) == (fx["text_bytes"], fx["vision_bytes"], fx["processor_bytes"], fx["bytes"])
     assert hashlib.sha256(img.tobytes()).hexdigest() == fx["sha256"]

@@ -519,6 +519,31 @@ def test_row_sharding_is_bit_identical(L, monkeypatch, cfg, q, world, mode):
     grp.close()
 
 
+@pytest.mark.parametrize("i", range(8))
+def test_row_sharding_on_random_geometries(L, monkeypatch, i):
+    """Two logical shards of geometries nothing was written against (slices below one quantisation group fall back to f32 payloads;
+    vocabularies with an unwritten tail; every family), full split on the odd cases."""
+    import dataclasses
+    rng = np.random.default_rng(3000 + i)
+    while True:
+        cfg = S.random_cfg(rng, i, max_pos=64)
+        if cfg.n_kv_heads == 2:
+            break
+    cfg = dataclasses.replace(cfg, vocab_size=cfg.vocab_size + cfg.vocab_size % 2)           # the world must divide the vocabulary
+    if i % 2: monkeypatch.setenv("LMRS_SHARD_SPLIT_OUT", "1")
+    q = [S.Q8_0, S.Q4_0][(i // 2) % 2]
+    img = S.build_image(cfg, q, seed=90 + i, threads=1)
+    grp = L.ShardGroup(img, 2); orc = O.Oracle(img)
+    tok = int(rng.integers(0, cfg.vocab_size))
+    for pos in range(8):
+        lg, nxt = grp.forward(tok, pos)
+        lo = orc.forward(tok, pos)
+        assert_bit_equal(lg, lo, f"{cfg} q{q} two shards, logits at pos {pos}")
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+        assert nxt == tok
+    grp.close()
+
+
 def _p2p_rank(rank, world, img_path, cfg, env, q_in, q_out):
     """One process of the peer-to-peer test: its shard of the model on device 0, handles exchanged through the parent."""
     try:

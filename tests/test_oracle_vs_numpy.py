@@ -42,11 +42,13 @@ def test_ops_match_numpy():
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
 
 
-def test_image_projector_oracle_matches_numpy_transcription():
-    """processor.rs:234-342: the C restatement against a reshape/transpose statement of the HD transform and the numpy Q8 ops,
-    on rows that cover the sub-image body, a row separator, glb_GN, the global crop and its last separator."""
+@pytest.mark.parametrize("q", [S.Q8_0, S.Q4_0, S.Q_NONE])
+def test_image_projector_oracle_matches_numpy_transcription(q):
+    """processor.rs:234-342: the C restatement against a reshape/transpose statement of the HD transform and the numpy ops,
+    on rows that cover the sub-image body, a row separator, glb_GN, the global crop and its last separator; Q8_0, Q4_0 and
+    unquantised sections."""
     from tools import synth_vision as V
-    sec = V.build_processor_section(seed=11)
+    sec = V.build_processor_section(seed=11, q_type=q)
     orc = O.ProcessorOracle(sec)
     rng = np.random.default_rng(4)
     w_crop, h_crop = 2, 1
@@ -60,13 +62,15 @@ def test_image_projector_oracle_matches_numpy_transcription():
         assert (got[r].view(np.uint32) == ref[r].view(np.uint32)).all(), f"embedding {r}: {np.flatnonzero(got[r] != ref[r])[:5]}"
 
 
-def test_vision_tower_oracle_matches_numpy_transcription():
-    """vision.rs:244-577 at the real ViT-L/14-336 geometry, one encoder layer, one crop: the C restatement against a
-    vectorised numpy statement written from the Rust source (patch conv with the matmul_rest tail, f32x8 lane sums,
-    sequential softmax sum, shared row quantisation for q/k/v, QuickGELU through libm expf)."""
+@pytest.mark.parametrize("q,small", [(S.Q8_0, False), (S.Q4_0, False), (S.Q_NONE, True), (S.Q4_0, True)])
+def test_vision_tower_oracle_matches_numpy_transcription(q, small):
+    """vision.rs:244-577 at the real ViT-L/14-336 geometry (small: 128 wide, 2 heads, two encoder layers run), one crop: the C
+    restatement against a vectorised numpy statement written from the Rust source (patch conv with the matmul_rest tail, f32x8
+    lane sums, sequential softmax sum, shared row quantisation for q/k/v, QuickGELU through libm expf); Q8_0, Q4_0 and
+    unquantised sections."""
     from tools import synth_vision as V
-    cfg = V.VisionCfg(n_layers=2)
-    sec = V.build_vision_section(cfg, seed=21)
+    cfg = V.VisionCfg(dim=128, hidden_dim=512, n_layers=3, n_heads=2, head_size=64) if small else V.VisionCfg(n_layers=2)
+    sec = V.build_vision_section(cfg, seed=21, q_type=q)
     orc = O.VisionOracle(sec)
     pv = V.pixel_values(cfg, 1, seed=8)
     ref = orc.forward(pv, 1)[0]

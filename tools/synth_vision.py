@@ -1,6 +1,6 @@
 """Synthetic vision section of an LMRS multimodal file (reference export.py:126-170, read back by
 src/vision.rs:99-243): CLIP ViT-L/14-336 shapes (the reference hard-codes 577 positions, vision.rs:117, and C = 1024, H = 24 in
-the processor), Q8_0, any number of layers.  Same conventions as tools/synth_lmrs.py: seeded numpy generator per tensor, weights
+the processor), Q8_0 / Q4_0 / f32, any number of layers.  Same conventions as tools/synth_lmrs.py: seeded numpy generator per tensor, weights
 quantised with the restated exporter quantiser."""
 from __future__ import annotations
 
@@ -9,7 +9,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from tools.synth_lmrs import Q8_0, quantize_q80
+from tools.synth_lmrs import Q4_0, Q8_0, Q_NONE, quantize_q40, quantize_q80
 
 
 @dataclass(frozen=True)
@@ -66,21 +66,21 @@ def vision_tensors(cfg: VisionCfg = VisionCfg(), seed: int = 99):
     return t
 
 
-def _section(header: bytes, tensors, gs: int) -> np.ndarray:
+def _section(header: bytes, tensors, gs: int, q_type: int = Q8_0) -> np.ndarray:
     parts = [np.frombuffer(header, np.uint8)]
     for _, arrays, quant in tensors:
         for a in arrays:
-            if quant:
-                q, sc = quantize_q80(np.ascontiguousarray(a, np.float32).reshape(a.shape[0], -1), gs)
+            if quant and q_type != Q_NONE:
+                q, sc = (quantize_q80 if q_type == Q8_0 else quantize_q40)(np.ascontiguousarray(a, np.float32).reshape(a.shape[0], -1), gs)
                 parts.append(q.view(np.uint8).reshape(-1)); parts.append(np.ascontiguousarray(sc, np.float32).reshape(-1).view(np.uint8))
             else:
                 parts.append(np.ascontiguousarray(a, np.float32).reshape(-1).view(np.uint8))
     return np.concatenate(parts)
 
 
-def build_vision_section(cfg: VisionCfg = VisionCfg(), seed: int = 99, gs: int = 128) -> np.ndarray:
-    """-> uint8 array: 128-byte header + tensors in the order VisionTransformer::new reads them (Q8_0)."""
-    return _section(vision_header(cfg, Q8_0, gs), vision_tensors(cfg, seed), gs)
+def build_vision_section(cfg: VisionCfg = VisionCfg(), seed: int = 99, gs: int = 128, q_type: int = Q8_0) -> np.ndarray:
+    """-> uint8 array: 128-byte header + tensors in the order VisionTransformer::new reads them (Q8_0 / Q4_0 / plain f32)."""
+    return _section(vision_header(cfg, q_type, gs), vision_tensors(cfg, seed), gs, q_type)
 
 
 def pixel_values(cfg: VisionCfg, num_crops: int, seed: int = 7) -> np.ndarray:
@@ -111,10 +111,10 @@ def processor_header(hidden_dim: int, text_dim: int, q_type: int = Q8_0, gs: int
     return h + b"\0" * (128 - len(h))
 
 
-def build_processor_section(hidden_dim: int = 4096, text_dim: int = 3072, seed: int = 123, gs: int = 128) -> np.ndarray:
+def build_processor_section(hidden_dim: int = 4096, text_dim: int = 3072, seed: int = 123, gs: int = 128, q_type: int = Q8_0) -> np.ndarray:
     """Processor section (export.py:155-170, read back by src/processor.rs:168-232): 13-byte header padded to 128, glb_GN,
     sub_GN, the two projector matrices (Q8_0), their biases."""
-    return _section(processor_header(hidden_dim, text_dim, Q8_0, gs), processor_tensors(hidden_dim, text_dim, seed), gs)
+    return _section(processor_header(hidden_dim, text_dim, q_type, gs), processor_tensors(hidden_dim, text_dim, seed), gs, q_type)
 
 
 def hf_vision_state_dict(cfg: VisionCfg, hidden_dim: int, text_dim: int, vseed: int, pseed: int) -> dict:

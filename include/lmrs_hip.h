@@ -177,7 +177,8 @@ int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* a
 /* ---- CLIP image tower of the multimodal models  (src/vision.rs) ---------------------------
  * lmrs_vision_create   <- VisionTransformer::new(data) -> (VisionTransformer, usize)   vision.rs:99-243
  *   `section` points at the vision section of an LMRS multimodal file (offset = *bytes_consumed of lmrs_create);
- *   *bytes_consumed = size of the section (the processor section follows).  Q8_0, CLIP ViT-L/14-336 geometry.
+ *   *bytes_consumed = size of the section (the processor section follows).  CLIP ViT-L/14-336 geometry; Q8_0 (the tuned path),
+ *   Q4_0 (quantize_q4 rows, matmul_q4 from packed nibbles on the matrix cores) and q_type None (the f32 `matmul`, correct, not tuned).
  * lmrs_vision_forward  <- VisionTransformer::forward(pixel_values, num_crops) -> (Vec<f32>, u32)   vision.rs:244-577
  *   pixel_values: num_crops * 3 * image_size^2 floats, normalised and cut into patches as PHI3VProcessor::process
  *   produces them; out: num_crops * 576 * dim floats (class token dropped); *new_shape = 576 * dim.
@@ -189,7 +190,7 @@ void lmrs_vision_destroy(lmrs_vision* v);
 int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, uint32_t num_crops, float* out, uint32_t* new_shape);
 
 /* --------------------------------------------------------------------------------------------------------------------------
- * Image projector of the multimodal models (reference src/processor.rs, struct PHI3VProcessor).  Q8_0 sections.
+ * Image projector of the multimodal models (reference src/processor.rs, struct PHI3VProcessor).  Q8_0, Q4_0 and unquantised sections.
  *
  * lmrs_processor_create   <- PHI3VProcessor::new(data) -> PHI3VProcessor              processor.rs:168-232
  *     section = the bytes that follow the vision tower's section in the model file (128-byte header: hidden_dim, text_dim,

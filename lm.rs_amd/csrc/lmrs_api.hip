@@ -713,7 +713,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     const lmrs_args& a = lay.args;
     const bool f32w = a.q_type == LMRS_Q_NONE;
     if (f32w && (world > 1 || uid)) return fail("q_type None (f32 weights) runs on one GPU only (row sharding is built for the quantised path)");
-    if (!f32w && a.group_size != 128) return fail("group_size != 128 is not supported by the HIP kernels (the reference exporter always quantises with 128)");
+    if (!f32w && a.group_size != 128) return fail("group_size != 128 is not supported: export.py quantises with 128 whatever --group-size says and only writes the value into the header (utils/io.py:21), so such a file is not readable by the reference either");
     const size_t dim = a.dim, att = (size_t)a.n_heads * a.head_size, kv = (size_t)a.n_kv_heads * a.head_size, hid = a.hidden_dim, V = a.vocab_size;
     if (dim % 128 || att % 128 || hid % 128) return fail("dim, n_heads*head_size and hidden_dim must be multiples of 128");
     if (dim > 10240 || att > 10240 || hid > 16384) return fail("vector lengths above 10240 (dim, attention) / 16384 (hidden) are not supported");
@@ -1540,15 +1540,16 @@ extern "C" int lmrs_op_expf(int device, float* y, const float* x, size_t n) {
 
 
 // ==================================================================================================
-// CLIP vision tower (reference src/vision.rs): VisionTransformer::new :99-243, forward :244-577.  Q8_0 sections.
+// CLIP vision tower (reference src/vision.rs): VisionTransformer::new :99-243, forward :244-577.  Q8_0 (tuned), Q4_0 and f32 sections.
 // ==================================================================================================
 struct VisLayer {
     float *ln1 = nullptr, *ln1_b = nullptr, *ln2 = nullptr, *ln2_b = nullptr, *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
-    int8_t *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr; float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;
+    char *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr; float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // weights: int8 / packed nibbles / f32; scales (quantised only)
 };
 struct lmrs_vision {
     int device = 0; hipStream_t stream = nullptr;
     uint32_t dim = 0, hidden = 0, n_layers = 0, n_heads = 0, head_size = 0, patch = 0, image = 0, gs = 0; float eps = 0;
+    int qt = LMRS_Q8_0;                            // q_type of the section: Q8_0, Q4_0 or None (f32)
     float *class_emb = nullptr, *patch_emb = nullptr, *pos_emb = nullptr, *pre_ln = nullptr, *pre_ln_b = nullptr;
     std::vector<VisLayer> layers;
     std::vector<void*> owned;
@@ -1587,13 +1588,19 @@ extern "C" int lmrs_vision_create(const uint8_t* sec, size_t len, int device, lm
     memcpy(&v->eps, sec + 20, 4); v->patch = rd32(sec + 24); v->image = rd32(sec + 28);
     const uint8_t q_type = sec[32]; v->gs = rd32(sec + 33);
     auto bad = [&](const char* m) { lmrs_vision_destroy(v); return fail(m); };
-    if (q_type != LMRS_Q8_0 || v->gs != 128) return bad("the vision tower is built for Q8_0 sections with group size 128");
+    if (q_type != LMRS_Q8_0 && q_type != LMRS_Q4_0 && q_type != LMRS_Q_NONE) return bad("vision section: unknown q_type");
+    if (q_type != LMRS_Q_NONE && v->gs != 128) return bad("the vision tower is built for quantised sections with group size 128 (what the exporter writes)");
+    v->qt = q_type;
     // the reference hard-codes 577 positions (vision.rs:117); the kernels are built for CLIP ViT-L/14-336 geometry
     if (v->dim != 1024 || v->head_size != 64 || v->n_heads * v->head_size != v->dim || v->patch == 0 || (v->image / v->patch) * (v->image / v->patch) != 576 ||
         v->hidden % 256 || v->hidden != 4096 || v->n_layers < 2)
         return bad("unsupported vision geometry (built for CLIP ViT-L/14-336: dim 1024, 16 heads of 64, 576 patches, hidden 4096)");
-    const size_t dim = v->dim, L = v->n_layers, hid = v->hidden, kdim = 3ull * v->patch * v->patch, G = dim / 128, GH = hid / 128;
-    const size_t need = 128 + 4 * (dim + dim * kdim + dim * 577 + 8 * L * dim + L * hid + L * dim + 2 * dim) + L * (4 * (dim * dim + dim * G * 4) + 2 * (dim * hid + dim * GH * 4));
+    const size_t dim = v->dim, L = v->n_layers, hid = v->hidden, kdim = 3ull * v->patch * v->patch;
+    // bytes of a weight tensor's values / group scales: int8, packed nibbles (init_param_quant, transformer.rs:24-48) or plain f32
+    auto qb = [&](size_t cnt) { return q_type == LMRS_Q_NONE ? cnt * 4 : (q_type == LMRS_Q4_0 ? cnt / 2 : cnt); };
+    auto sb = [&](size_t cnt) { return q_type == LMRS_Q_NONE ? (size_t)0 : cnt / 128 * 4; };
+    const size_t need = 128 + 4 * (dim + dim * kdim + dim * 577 + 8 * L * dim + L * hid + L * dim + 2 * dim) +
+                        L * (4 * (qb(dim * dim) + sb(dim * dim)) + 2 * (qb(dim * hid) + sb(dim * hid)));
     if (len < need) return bad("vision section truncated");
     if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) return bad("hipStreamCreate failed");
     size_t off = 128;
@@ -1603,11 +1610,11 @@ extern "C" int lmrs_vision_create(const uint8_t* sec, size_t len, int device, lm
     v->pos_emb = vis_dev<float>(v, f32v(dim * 577), dim * 577 * 4);
     v->layers.resize(L);
     const uint8_t *ln1 = f32v(L * dim), *ln1b = f32v(L * dim), *ln2 = f32v(L * dim), *ln2b = f32v(L * dim);
-    // quantised tensors: per layer {int8 [rows*cols], f32 scales [rows*cols/128]}, then the bias block of all layers
+    // weight tensors: per layer {values [rows*cols], f32 scales [rows*cols/128] (quantised only)}, then the bias block of all layers
     struct QT { const uint8_t* q[64]; const uint8_t* s[64]; const uint8_t* bias; };
     if (L > 64) return bad("too many vision layers");
     auto quant = [&](size_t rows, size_t cols, size_t bias_len, QT& t) {
-        for (size_t l = 0; l < L; ++l) { t.q[l] = sec + off; off += rows * cols; t.s[l] = sec + off; off += rows * cols / 128 * 4; }
+        for (size_t l = 0; l < L; ++l) { t.q[l] = sec + off; off += qb(rows * cols); t.s[l] = sec + off; off += sb(rows * cols); }
         t.bias = sec + off; off += L * bias_len * 4;
     };
     QT tq, tk, tv, to, t1, t2;
@@ -1616,23 +1623,24 @@ extern "C" int lmrs_vision_create(const uint8_t* sec, size_t len, int device, lm
     v->pre_ln = vis_dev<float>(v, f32v(dim), dim * 4);
     v->pre_ln_b = vis_dev<float>(v, f32v(dim), dim * 4);
     if (off != need) return bad("vision layout arithmetic");
+    const size_t qdd = qb(dim * dim), sdd = sb(dim * dim), qdh = qb(dim * hid), sdh = sb(dim * hid);
     for (size_t l = 0; l < L; ++l) {
         VisLayer& Y = v->layers[l];
         Y.ln1 = vis_dev<float>(v, ln1 + l * dim * 4, dim * 4); Y.ln1_b = vis_dev<float>(v, ln1b + l * dim * 4, dim * 4);
         Y.ln2 = vis_dev<float>(v, ln2 + l * dim * 4, dim * 4); Y.ln2_b = vis_dev<float>(v, ln2b + l * dim * 4, dim * 4);
         // q | k | v rows concatenated: one GEMM
-        Y.wqkv = vis_dev<int8_t>(v, nullptr, 3 * dim * dim); Y.sqkv = vis_dev<float>(v, nullptr, 3 * dim * G * 4); Y.bqkv = vis_dev<float>(v, nullptr, 3 * dim * 4);
+        Y.wqkv = vis_dev<char>(v, nullptr, 3 * qdd); Y.sqkv = vis_dev<float>(v, nullptr, 3 * sdd); Y.bqkv = vis_dev<float>(v, nullptr, 3 * dim * 4);
         if (!Y.wqkv || !Y.sqkv || !Y.bqkv) return bad("hipMalloc failed");
         const QT* three[3] = {&tq, &tk, &tv};
         for (int w = 0; w < 3; ++w) {
-            if (hipMemcpy(Y.wqkv + (size_t)w * dim * dim, three[w]->q[l], dim * dim, hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(Y.sqkv + (size_t)w * dim * G, three[w]->s[l], dim * G * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            if (hipMemcpy(Y.wqkv + (size_t)w * qdd, three[w]->q[l], qdd, hipMemcpyHostToDevice) != hipSuccess ||
+                (sdd && hipMemcpy(reinterpret_cast<char*>(Y.sqkv) + (size_t)w * sdd, three[w]->s[l], sdd, hipMemcpyHostToDevice) != hipSuccess) ||
                 hipMemcpy(Y.bqkv + (size_t)w * dim, three[w]->bias + l * dim * 4, dim * 4, hipMemcpyHostToDevice) != hipSuccess)
                 return bad("upload of the vision weights failed");
         }
-        Y.wo = vis_dev<int8_t>(v, to.q[l], dim * dim); Y.so = vis_dev<float>(v, to.s[l], dim * G * 4); Y.bo = vis_dev<float>(v, to.bias + l * dim * 4, dim * 4);
-        Y.w1 = vis_dev<int8_t>(v, t1.q[l], hid * dim); Y.s1 = vis_dev<float>(v, t1.s[l], hid * G * 4); Y.b1 = vis_dev<float>(v, t1.bias + l * hid * 4, hid * 4);
-        Y.w2 = vis_dev<int8_t>(v, t2.q[l], dim * hid); Y.s2 = vis_dev<float>(v, t2.s[l], dim * GH * 4); Y.b2 = vis_dev<float>(v, t2.bias + l * dim * 4, dim * 4);
+        Y.wo = vis_dev<char>(v, to.q[l], qdd); Y.so = vis_dev<float>(v, to.s[l], sdd); Y.bo = vis_dev<float>(v, to.bias + l * dim * 4, dim * 4);
+        Y.w1 = vis_dev<char>(v, t1.q[l], qdh); Y.s1 = vis_dev<float>(v, t1.s[l], sdh); Y.b1 = vis_dev<float>(v, t1.bias + l * hid * 4, hid * 4);
+        Y.w2 = vis_dev<char>(v, t2.q[l], qdh); Y.s2 = vis_dev<float>(v, t2.s[l], sdh); Y.b2 = vis_dev<float>(v, t2.bias + l * dim * 4, dim * 4);
         if (!Y.ln1 || !Y.ln1_b || !Y.ln2 || !Y.ln2_b || !Y.wo || !Y.so || !Y.bo || !Y.w1 || !Y.s1 || !Y.b1 || !Y.w2 || !Y.s2 || !Y.b2) return bad("hipMalloc failed");
     }
     if (!v->class_emb || !v->patch_emb || !v->pos_emb || !v->pre_ln || !v->pre_ln_b) return bad("hipMalloc failed");
@@ -1674,23 +1682,33 @@ extern "C" int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, ui
     VisPatchArgs pa{v->pix, v->patch_emb, v->class_emb, v->pos_emb, v->E, dim, 576, (int)(3 * v->patch * v->patch)};
     HIP_OK(launch_vis_patch_embed(pa, (int)num_crops, s));
     HIP_OK(launch_vis_layernorm(v->E, v->pre_ln, v->pre_ln_b, v->eps, dim, n_tok, v->X, nullptr, nullptr, s));     // input layernorm (:293-301)
+    // One projection of the whole batch: quantise the rows with the section's quantiser (Q8_0: fused into the layernorm where
+    // there is one; Q4_0: rows_prologue_kernel's Q4 flavour) and run the int8-MFMA GEMM, or the f32 matmul kernel (q_type None).
+    // src_f32: the rows [n_tok][n] (for Q8_0 with pre_quantised = true they are already in xq / xs).
+    auto project = [&](const float* src_f32, bool pre_quantised, const char* w, const float* ws, int n, int o, GemmArgs g, int epi) -> int {
+        g.wq = w; g.ws = ws; g.n = n; g.o = o; g.n_tok = n_tok;
+        if (v->qt == LMRS_Q_NONE) { g.xf = src_f32; HIP_OK(launch_matmul_f32_rows(g, epi, s)); return 0; }
+        if (!pre_quantised) HIP_OK(launch_rows_prologue(const_cast<float*>(src_f32), nullptr, nullptr, nullptr, 0.f, 0, 0, v->qt == LMRS_Q4_0, n, n_tok, v->xq, v->xs, s));
+        g.xq = v->xq; g.xs = v->xs; g.q4 = v->qt == LMRS_Q4_0;
+        HIP_OK(launch_gemm_q8(g, epi, s));
+        return 0;
+    };
+    const bool q8 = v->qt == LMRS_Q8_0;
     for (uint32_t l = 0; l + 1 < v->n_layers; ++l) {                      // the penultimate layer's output is used (:303)
         const VisLayer& Y = v->layers[l];
+        // layernorm 1 (Q8_0: quantised in the same launch; otherwise f32 rows into AO, which is free until the attention writes it)
+        HIP_OK(launch_vis_layernorm(v->X, Y.ln1, Y.ln1_b, v->eps, dim, n_tok, q8 ? nullptr : v->AO, v->xq, v->xs, s));
         GemmArgs g{};
-        g.xq = v->xq; g.xs = v->xs; g.n_tok = n_tok;
-        HIP_OK(launch_vis_layernorm(v->X, Y.ln1, Y.ln1_b, v->eps, dim, n_tok, nullptr, v->xq, v->xs, s));
-        g.wq = Y.wqkv; g.ws = Y.sqkv; g.n = dim; g.o = 3 * dim; g.out = v->QKV; g.bias = Y.bqkv; g.att_dim = dim; g.qscale = sqrtf((float)v->head_size);
-        HIP_OK(launch_gemm_q8(g, EPI_VQKV, s));
+        g.out = v->QKV; g.bias = Y.bqkv; g.att_dim = dim; g.qscale = sqrtf((float)v->head_size);
+        if (project(v->AO, q8, Y.wqkv, Y.sqkv, dim, 3 * dim, g, EPI_VQKV)) return -1;
         HIP_OK(launch_vis_attention(v->QKV, v->AO, v->scratch, (int)num_crops, (int)v->n_heads, T, dim, s));
-        HIP_OK(launch_rows_prologue(v->AO, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, dim, n_tok, v->xq, v->xs, s));
-        g.wq = Y.wo; g.ws = Y.so; g.n = dim; g.o = dim; g.out = v->E; g.bias = Y.bo; g.resid = v->X;
-        HIP_OK(launch_gemm_q8(g, EPI_BIAS_RESID, s));
-        HIP_OK(launch_vis_layernorm(v->E, Y.ln2, Y.ln2_b, v->eps, dim, n_tok, nullptr, v->xq, v->xs, s));
-        g.wq = Y.w1; g.ws = Y.s1; g.n = dim; g.o = hid; g.out = v->H; g.bias = Y.b1; g.resid = nullptr;
-        HIP_OK(launch_gemm_q8(g, EPI_BIAS_QGELU, s));
-        HIP_OK(launch_rows_prologue(v->H, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, hid, n_tok, v->xq, v->xs, s));
-        g.wq = Y.w2; g.ws = Y.s2; g.n = hid; g.o = dim; g.out = v->X; g.bias = Y.b2; g.resid = v->E;
-        HIP_OK(launch_gemm_q8(g, EPI_BIAS_RESID, s));
+        g = GemmArgs{}; g.out = v->E; g.bias = Y.bo; g.resid = v->X;
+        if (project(v->AO, false, Y.wo, Y.so, dim, dim, g, EPI_BIAS_RESID)) return -1;
+        HIP_OK(launch_vis_layernorm(v->E, Y.ln2, Y.ln2_b, v->eps, dim, n_tok, q8 ? nullptr : v->AO, v->xq, v->xs, s));
+        g = GemmArgs{}; g.out = v->H; g.bias = Y.b1;
+        if (project(v->AO, q8, Y.w1, Y.s1, dim, hid, g, EPI_BIAS_QGELU)) return -1;
+        g = GemmArgs{}; g.out = v->X; g.bias = Y.b2; g.resid = v->E;
+        if (project(v->H, false, Y.w2, Y.s2, hid, dim, g, EPI_BIAS_RESID)) return -1;
     }
     for (uint32_t c = 0; c < num_crops; ++c)                               // drop the CLS embedding (:571-579)
         HIP_OK(hipMemcpyAsync(out + (size_t)c * 576 * dim, v->X + ((size_t)c * T + 1) * dim, (size_t)576 * dim * 4, hipMemcpyDeviceToHost, s));
@@ -1707,9 +1725,9 @@ extern "C" int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, ui
 // ==================================================================================================
 struct lmrs_processor {
     int device = 0; hipStream_t stream = nullptr;
-    uint32_t hidden = 0, text = 0;
+    uint32_t hidden = 0, text = 0; int qt = LMRS_Q8_0;       // q_type of the section: Q8_0, Q4_0 or None (f32)
     std::vector<float> glb_gn, sub_gn;
-    int8_t *p0 = nullptr, *p1 = nullptr; float *s0 = nullptr, *s1 = nullptr, *b0 = nullptr, *b1 = nullptr;
+    char *p0 = nullptr, *p1 = nullptr; float *s0 = nullptr, *s1 = nullptr, *b0 = nullptr, *b1 = nullptr;
     size_t cap = 0; float *emb = nullptr, *hid = nullptr, *outd = nullptr, *xs = nullptr; int8_t* xq = nullptr;
 };
 
@@ -1730,19 +1748,25 @@ extern "C" int lmrs_processor_create(const uint8_t* sec, size_t len, int device,
     p->device = device; p->hidden = rd32(sec); p->text = rd32(sec + 4);
     const uint8_t q_type = sec[8]; const uint32_t gs = rd32(sec + 9);
     auto bad = [&](const char* m) { lmrs_processor_destroy(p); return fail(m); };
-    if (q_type != LMRS_Q8_0 || gs != 128) return bad("the image projector is built for Q8_0 sections with group size 128");
+    if (q_type != LMRS_Q8_0 && q_type != LMRS_Q4_0 && q_type != LMRS_Q_NONE) return bad("processor section: unknown q_type");
+    if (q_type != LMRS_Q_NONE && gs != 128) return bad("the image projector is built for quantised sections with group size 128 (what the exporter writes)");
+    p->qt = q_type;
     // reshape_hd_patches_2x2merge hard-codes C = 1024 (processor.rs:378): hidden_dim = 4 * 1024
     if (p->hidden != 4096 || !rows_prologue_supported((int)p->text) || p->text % 16) return bad("unsupported projector geometry (4096 -> text_dim in {2048, 3072})");
     const size_t H = p->hidden, Tt = p->text;
-    const size_t need = 128 + 4 * (2 * H + 2 * Tt) + (Tt * H + Tt * H / 128 * 4) + (Tt * Tt + Tt * Tt / 128 * 4);
+    auto qb = [&](size_t cnt) { return q_type == LMRS_Q_NONE ? cnt * 4 : (q_type == LMRS_Q4_0 ? cnt / 2 : cnt); };
+    auto sb = [&](size_t cnt) { return q_type == LMRS_Q_NONE ? (size_t)0 : cnt / 128 * 4; };
+    const size_t need = 128 + 4 * (2 * H + 2 * Tt) + qb(Tt * H) + sb(Tt * H) + qb(Tt * Tt) + sb(Tt * Tt);
     if (len < need) return bad("processor section truncated");
     if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) return bad("hipStreamCreate failed");
     size_t off = 128;
     p->glb_gn.assign(reinterpret_cast<const float*>(sec + off), reinterpret_cast<const float*>(sec + off) + H); off += H * 4;
     p->sub_gn.assign(reinterpret_cast<const float*>(sec + off), reinterpret_cast<const float*>(sec + off) + H); off += H * 4;
-    auto up = [&](void** dst, size_t bytes) { if (hipMalloc(dst, bytes) != hipSuccess) return false; const bool ok = hipMemcpy(*dst, sec + off, bytes, hipMemcpyHostToDevice) == hipSuccess; off += bytes; return ok; };
-    if (!up(reinterpret_cast<void**>(&p->p0), Tt * H) || !up(reinterpret_cast<void**>(&p->s0), Tt * H / 128 * 4) || !up(reinterpret_cast<void**>(&p->p1), Tt * Tt) ||
-        !up(reinterpret_cast<void**>(&p->s1), Tt * Tt / 128 * 4) || !up(reinterpret_cast<void**>(&p->b0), Tt * 4) || !up(reinterpret_cast<void**>(&p->b1), Tt * 4))
+    auto up = [&](void** dst, size_t bytes) {
+        if (hipMalloc(dst, bytes ? bytes : 4) != hipSuccess) return false;
+        const bool ok = !bytes || hipMemcpy(*dst, sec + off, bytes, hipMemcpyHostToDevice) == hipSuccess; off += bytes; return ok; };
+    if (!up(reinterpret_cast<void**>(&p->p0), qb(Tt * H)) || !up(reinterpret_cast<void**>(&p->s0), sb(Tt * H)) || !up(reinterpret_cast<void**>(&p->p1), qb(Tt * Tt)) ||
+        !up(reinterpret_cast<void**>(&p->s1), sb(Tt * Tt)) || !up(reinterpret_cast<void**>(&p->b0), Tt * 4) || !up(reinterpret_cast<void**>(&p->b1), Tt * 4))
         return bad("hipMalloc / upload failed");
     if (bytes_consumed) *bytes_consumed = off;
     *out = p;
@@ -1823,14 +1847,18 @@ extern "C" int lmrs_processor_forward(lmrs_processor* p, const float* out_patche
     }
     hipStream_t s = p->stream;
     HIP_OK(hipMemcpyAsync(p->emb, emb.data(), ne * H * 4, hipMemcpyHostToDevice, s));
-    GemmArgs g{};
-    g.xq = p->xq; g.xs = p->xs; g.n_tok = (int)ne;
-    HIP_OK(launch_rows_prologue(p->emb, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, (int)H, (int)ne, p->xq, p->xs, s));
-    g.wq = p->p0; g.ws = p->s0; g.n = (int)H; g.o = (int)Tt; g.out = p->hid; g.bias = p->b0;
-    HIP_OK(launch_gemm_q8(g, EPI_BIAS_GELU, s));
-    HIP_OK(launch_rows_prologue(p->hid, nullptr, nullptr, nullptr, 0.f, 0, 0, 0, (int)Tt, (int)ne, p->xq, p->xs, s));
-    g.wq = p->p1; g.ws = p->s1; g.n = (int)Tt; g.o = (int)Tt; g.out = p->outd; g.bias = p->b1;
-    HIP_OK(launch_gemm_q8(g, EPI_BIAS, s));
+    // the two matmuls of every row (processor.rs:262-336): the section's quantiser + the int8-MFMA GEMM, or the f32 matmul kernel
+    auto project = [&](float* src, const char* w, const float* ws, size_t n, float* dst, const float* bias, int epi) -> int {
+        GemmArgs g{};
+        g.wq = w; g.ws = ws; g.n = (int)n; g.o = (int)Tt; g.n_tok = (int)ne; g.out = dst; g.bias = bias;
+        if (p->qt == LMRS_Q_NONE) { g.xf = src; HIP_OK(launch_matmul_f32_rows(g, epi, s)); return 0; }
+        HIP_OK(launch_rows_prologue(src, nullptr, nullptr, nullptr, 0.f, 0, 0, p->qt == LMRS_Q4_0, (int)n, (int)ne, p->xq, p->xs, s));
+        g.xq = p->xq; g.xs = p->xs; g.q4 = p->qt == LMRS_Q4_0;
+        HIP_OK(launch_gemm_q8(g, epi, s));
+        return 0;
+    };
+    if (project(p->emb, p->p0, p->s0, H, p->hid, p->b0, EPI_BIAS_GELU)) return -1;
+    if (project(p->hid, p->p1, p->s1, Tt, p->outd, p->b1, EPI_BIAS)) return -1;
     HIP_OK(hipMemcpyAsync(out, p->outd, ne * Tt * 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     if (n_embeds) *n_embeds = (uint32_t)ne;

@@ -121,12 +121,14 @@ hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s);
 struct GemmArgs {
     const void* wq; const float* ws;     // weights [o][n] int8 + scales [o][n/128]
     const int8_t* xq; const float* xs;   // activations [n_tok][n] int8 + scales [n_tok][n/128]
+    const float* xf;                     // launch_matmul_f32_rows only: activations [n_tok][n] f32 (wq then holds f32 weights [o][n])
     int n, o, n_tok; int q4;             // q4: weights [o][n/2] packed nibbles, activations int8 (q - 8), de-interleaved per 8
     float* out;                          // STORE / RESID: [n_tok][o]; SWIGLU: [n_tok][o/2]; QKV: q [n_tok][att_dim]
     float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer, pos0;    // EPI_QKV
     const float* bias; const float* resid; float qscale;                         // CLIP epilogues: bias [o], residual [n_tok][o], sqrt(head_size)
 };
 hipError_t launch_gemm_q8(const GemmArgs& a, int epi, hipStream_t s);
+hipError_t launch_matmul_f32_rows(const GemmArgs& a, int epi, hipStream_t s);   // q_type None sections of the image path (lmrs_f32.inc)
 bool rows_prologue_supported(int n);
 hipError_t launch_rows_prologue(float* x, const float* rms_w, const float* delta, const float* add_w, float eps, int add_unit, int mode, int q4,
                                 int n, int n_tok, int8_t* xq, float* xs, hipStream_t s);

@@ -1618,8 +1618,8 @@ hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#include "lmrs_f32.inc"
 #include "lmrs_prefill.inc"
+#include "lmrs_f32.inc"        // (its batched kernel uses the epilogues of lmrs_prefill.inc)
 #include "lmrs_vision.inc"
 #include "lmrs_fused.inc"
 

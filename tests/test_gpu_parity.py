@@ -678,6 +678,20 @@ def test_vision_tower_matches_the_cpu_path(L, n_layers, num_crops):
     assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"vision tower, {n_layers - 1} layer(s), {num_crops} crop(s)")
 
 
+@pytest.mark.parametrize("q,n_layers,num_crops", [(S.Q4_0, 3, 2), (S.Q_NONE, 2, 1), (S.Q_NONE, 3, 2)])
+def test_vision_tower_with_q4_and_unquantised_sections(L, q, n_layers, num_crops):
+    """The other two section types export.py writes for the tower (vision.rs:110-243): Q4_0 - quantize_q4 of every row, matmul_q4 on
+    the matrix cores from packed nibbles - and q_type None - the f32 `matmul` (chunk sums through wide's tree, added in order)."""
+    from tools import synth_vision as V
+    cfg = V.VisionCfg(n_layers=n_layers)
+    sec = V.build_vision_section(cfg, seed=15 + n_layers, q_type=q)
+    dev = L.VisionTransformer(sec); orc = O.VisionOracle(sec)
+    assert dev.bytes_consumed == orc.bytes_consumed == sec.size
+    pv = V.pixel_values(cfg, num_crops, seed=4)
+    got = dev.forward(pv, num_crops); ref = orc.forward(pv, num_crops)
+    assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"vision tower q_type {q}, {n_layers - 1} layer(s), {num_crops} crop(s)")
+
+
 def test_vision_tower_at_full_depth(L):
     """The tower as configs[4] runs it: 24 layers in the file, 23 executed (vision.rs:303), global crop + one sub-image."""
     from tools import synth_vision as V
@@ -688,11 +702,11 @@ def test_vision_tower_at_full_depth(L):
     assert_bit_equal(dev.forward(pv, 2).reshape(-1), orc.forward(pv, 2).reshape(-1), "vision tower, 23 layers, 2 crops")
 
 
-def _multimodal_file(text_cfg, vis_layers, seed):
+def _multimodal_file(text_cfg, vis_layers, seed, q=S.Q8_0):
     from tools import synth_vision as V
-    text = S.build_image(text_cfg, S.Q8_0, seed=seed, multimodal=1)
+    text = S.build_image(text_cfg, q, seed=seed, multimodal=1)
     vcfg = V.VisionCfg(n_layers=vis_layers)
-    return np.concatenate([text, V.build_vision_section(vcfg, seed=seed + 1), V.build_processor_section(seed=seed + 2)]), vcfg
+    return np.concatenate([text, V.build_vision_section(vcfg, seed=seed + 1, q_type=q), V.build_processor_section(seed=seed + 2, q_type=q)]), vcfg
 
 
 def _image_prefill(model, vision, processor, pv, num_crops, w_crop, h_crop, bos_image, bos_text):
@@ -704,15 +718,16 @@ def _image_prefill(model, vision, processor, pv, num_crops, w_crop, h_crop, bos_
     return emb, model.fill_kv_cache(emb, 0), img
 
 
-@pytest.mark.parametrize("text_cfg,vis_layers", [("mini-phi-long", 3), ("phi-3.5", 24)])
-def test_multimodal_prefill_end_to_end(L, text_cfg, vis_layers):
+@pytest.mark.parametrize("text_cfg,vis_layers,q", [("mini-phi-long", 3, S.Q8_0), ("phi-3.5", 24, S.Q8_0), ("mini-phi-long", 3, S.Q4_0), ("mini-phi-long", 2, S.Q_NONE)])
+def test_multimodal_prefill_end_to_end(L, text_cfg, vis_layers, q):
     """BASELINE.json configs[4] in the reference's call order (src/bin/chat.rs:84-121): Transformer::new, VisionTransformer::new at
     the offset it returned, PHI3VProcessor::new after the vision section; vision.forward -> processor.forward -> the 313 image
     features spliced between two get_embeddings blocks (4 + 313 + 3 = 320 embeddings) -> fill_kv_cache(320) -> 8 greedy decode
     steps on the prefilled cache.  Every stage bit-equal to the CPU path: image features, the mutated embeddings, the token ids,
-    the logits of one more step and KV rows inside the image span.  ("phi-3.5", 24): everything at full size."""
+    the logits of one more step and KV rows inside the image span.  ("phi-3.5", 24): everything at full size; Q4_0 / q_type None:
+    the whole file - text, tower, projector - in the exporter's other two formats."""
     from tools import synth_vision as V
-    data, vcfg = _multimodal_file(text_cfg, vis_layers, seed=31)
+    data, vcfg = _multimodal_file(text_cfg, vis_layers, seed=31, q=q)
     m = L.Transformer(data); orc = O.Oracle(data)
     assert m.args.multimodal == 1 and m.bytes_consumed == orc.bytes_consumed
     off = m.bytes_consumed
@@ -785,6 +800,18 @@ def test_image_projector_matches_the_cpu_path(L, w_crop, h_crop):
     got = dev.forward(feats, 576 * 1024, 12, w_crop, h_crop); ref = orc.forward(feats, 576 * 1024, 12, w_crop, h_crop)
     assert got.shape == ref.shape == ((h_crop * 12) * (w_crop * 12 + 1) + 12 * 13 + 1, 3072)
     assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"image projector, {w_crop}x{h_crop} sub-images")
+
+
+@pytest.mark.parametrize("q,text_dim", [(S.Q4_0, 3072), (S.Q_NONE, 3072), (S.Q4_0, 2048)])
+def test_image_projector_with_q4_and_unquantised_sections(L, q, text_dim):
+    from tools import synth_vision as V
+    sec = V.build_processor_section(text_dim=text_dim, seed=12, q_type=q)
+    dev = L.PHI3VProcessor(sec); orc = O.ProcessorOracle(sec)
+    assert dev.bytes_consumed == orc.bytes_consumed == sec.size
+    feats = (np.random.default_rng(19).standard_normal((3, 576, 1024)) * 1.5).astype(np.float32)
+    got = dev.forward(feats, 576 * 1024, 12, 2, 1); ref = orc.forward(feats, 576 * 1024, 12, 2, 1)
+    assert got.shape == ref.shape
+    assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"image projector q_type {q}, text_dim {text_dim}")
 
 
 def test_image_projector_rejects_bad_geometry(L):

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Regenerates the round's measurement artefacts on a GPU box (run from the repo root through gpurun); everything lands in
+# gpurun_out/art/ and is copied into profiles/ by hand afterwards.  PMC counters are collected in their own rocprofv3 runs
+# (--kernel-trace only, one counter per pass), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
+#   usage: bash tools/make_profiles.sh <tag>            (e.g. r2)
+set -u
+TAG=${1:-r2}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/art; rm -rf $OUT; mkdir -p $OUT
+pmc() {   # model qtype out-json
+    for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
+    done
+    f=$(ls $OUT/pmc_$1_FETCH_SIZE/*/*counter_collection.csv | head -1); w=$(ls $OUT/pmc_$1_WRITE_SIZE/*/*counter_collection.csv | head -1)
+    python tools/pmc_summary.py "$f" "$w" $3 $1 $2
+    cp $3 profiles/                                   # bench.py reads profiles/*traffic*.json (matching model / qtype / source hash)
+    rm -rf $OUT/pmc_$1_FETCH_SIZE $OUT/pmc_$1_WRITE_SIZE
+}
+pmc llama-3.2-1b q8_0 $OUT/${TAG}_traffic_llama1b_q8.json
+pmc gemma-2-2b q4_0 $OUT/${TAG}_traffic_gemma2b_q4.json
+timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --cpu-steps 0 > $OUT/stats.log 2>&1
+cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv; rm -rf $OUT/stats
+timeout 300 python bench.py --model gemma-2-2b --qtype q4_0 --steps 64 > $OUT/${TAG}_bench_gemma2b_q4.json 2>> $OUT/bench.err
+timeout 400 python bench.py --model llama-3.2-3b --steps 64 > $OUT/${TAG}_bench_llama3b.json 2>> $OUT/bench.err
+timeout 400 python bench.py --model phi-3.5 --steps 64 > $OUT/${TAG}_bench_phi35.json 2>> $OUT/bench.err
+timeout 200 python tools/timeline.py llama-3.2-1b 100 > $OUT/${TAG}_timeline_llama1b.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf -- python tools/prefill_rate.py llama-3.2-1b 512 > $OUT/${TAG}_prefill512.log 2>&1
+cp $(ls $OUT/pf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prefill512_kernel_stats.csv; rm -rf $OUT/pf
+LMRS_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29581 bench.py --gpus 2 --steps 64 --warmup 16 --cpu-steps 8 2> $OUT/tp2.err | grep '^{' > $OUT/${TAG}_bench_tp2_two_ranks_one_device.json
+for f in $OUT/${TAG}_bench*.json; do python - "$f" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
+print(sys.argv[1].split("/")[-1], d["value"], "tok/s  frac", r.get("frac"), "traffic", r.get("traffic"), "parity", d.get("parity"))
+PY
+done

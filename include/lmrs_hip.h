@@ -213,6 +213,12 @@ int lmrs_processor_forward(lmrs_processor* p, const float* out_patches, uint32_t
 int lmrs_processor_hd_transform(const float* out_patches, uint32_t total_floats, uint32_t new_shape, uint32_t w_crop, uint32_t h_crop,
                                 const float* glb_gn, const float* sub_gn, float* out, uint32_t* n_embeds);
 
+/* Host-only verification aid (works without a GPU): the (cos, sin) pair lmrs_create tabulates for position `pos` and pair `j` of a
+ * head (j < head_size / 2) - the RoPE frequency arithmetic of transformer.rs:446-477 (Llama-3 wavelength scaling, Phi LongRoPE short
+ * factors and magnitude) for the model family / rope_theta / head_size in `args`.  Lets the tests check this host function against a
+ * transcription that shares no code with it. */
+int lmrs_rope_terms(const lmrs_args* args, uint32_t pos, uint32_t j, float* fcr, float* fci);
+
 /* --------------------------------------------------------------------------------------------------------------------------
  * The callers either side of the device path, HOST code with the reference's exact results (no GPU needed):
  *

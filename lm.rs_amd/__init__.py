@@ -30,7 +30,7 @@ EXPORTS = [
     "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
-    "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform",
+    "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
     "lmrs_tokenizer_create", "lmrs_tokenizer_destroy", "lmrs_tokenizer_info", "lmrs_tokenizer_encode", "lmrs_tokenizer_decode",
     "lmrs_sampler_create", "lmrs_sampler_destroy", "lmrs_sampler_sample",
 ]
@@ -108,6 +108,7 @@ def lib():
         L.lmrs_processor_destroy.restype = None
         L.lmrs_processor_forward.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, C.POINTER(u32)]
         L.lmrs_processor_hd_transform.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, C.POINTER(u32)]
+        L.lmrs_rope_terms.argtypes = [C.POINTER(TransformerArgs), u32, u32, f32p, f32p]
         L.lmrs_tokenizer_create.argtypes = [vp, sz, C.POINTER(vp)]
         L.lmrs_tokenizer_destroy.argtypes = [vp]; L.lmrs_tokenizer_destroy.restype = None
         L.lmrs_tokenizer_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
@@ -368,6 +369,14 @@ class VisionTransformer:
             self.close()
         except Exception:
             pass
+
+
+def rope_terms(model_type: int, rope_theta: float, head_size: int, pos: int, j: int):
+    """(cos, sin) of the RoPE table lmrs_create builds, for one position and pair index (host-only, no GPU)."""
+    a = TransformerArgs(); a.model_type = model_type; a.rope_theta = rope_theta; a.head_size = head_size
+    c, s_ = C.c_float(), C.c_float()
+    _chk(lib().lmrs_rope_terms(C.byref(a), pos, j, C.byref(c), C.byref(s_)))
+    return np.float32(c.value), np.float32(s_.value)
 
 
 def processor_hd_transform(out_patches: np.ndarray, w_crop: int, h_crop: int, glb_gn: np.ndarray, sub_gn: np.ndarray) -> np.ndarray:

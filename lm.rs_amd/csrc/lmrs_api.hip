@@ -147,6 +147,14 @@ void rope_terms(const lmrs_args& a, uint32_t p, uint32_t j, float* fcr, float* f
     *fci = sinf(val) * scaling_factor;
 }
 
+extern "C" int lmrs_rope_terms(const lmrs_args* args, uint32_t pos, uint32_t j, float* fcr, float* fci) {
+    if (!args || !fcr || !fci) return fail("NULL argument");
+    if (args->head_size < 2 || j >= args->head_size / 2) return fail("j must be below head_size / 2");
+    if (args->model_type == LMRS_PHI && args->head_size > 96) return fail("Phi: head_size above 96 indexes past the 48 LongRoPE short factors");
+    rope_terms(*args, pos, j, fcr, fci);
+    return 0;
+}
+
 // one decoder layer of an unquantised model (q_type None): the same launches with the f32 matmul (lmrs_f32.inc); Gemma's
 // x += rmsnorm(branch) steps as separate launches
 int enqueue_layer_f32(lmrs_ctx* c, int l) {

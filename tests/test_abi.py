@@ -112,3 +112,19 @@ def test_processor_hd_transform_on_the_host(w_crop, h_crop):
     ref = np.concatenate([NR.hd_transform(feats[1:], h_crop, w_crop, sub), glb.reshape(1, -1), NR.hd_transform(feats[:1], 1, 1, sub)])
     assert got.shape == ref.shape == ((h_crop * 12) * (w_crop * 12 + 1) + 12 * 13 + 1, 4096)
     assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("model_type,theta,hs", [(0, 10000.0, 256), (0, 10000.0, 128), (1, 500000.0, 64), (1, 500000.0, 128), (2, 10000.0, 96), (2, 10000.0, 64)])
+def test_rope_table_terms_on_the_host(model_type, theta, hs):
+    """The host function behind lmrs_create's RoPE table (transformer.rs:446-477: frequency, Llama-3 wavelength scaling with its three
+    regimes, Phi's LongRoPE short factors and magnitude) against the numpy transcription's rope(), which shares no code with it: every
+    pair index, positions across the whole 8192-position cache - bit for bit, no GPU involved."""
+    import types
+    import lmrs_amd
+    import numpy_ref as NR
+    ref = types.SimpleNamespace(theta=np.float32(theta), hs=hs, model_type=model_type)
+    for pos in list(range(0, 40)) + [63, 64, 127, 255, 256, 1000, 4095, 4096, 8191]:
+        for j in range(hs // 2):
+            c, s_ = lmrs_amd.rope_terms(model_type, theta, hs, pos, j)
+            rc, rs = NR.NumpyModel.rope(ref, pos, j)
+            assert np.float32(c).view(np.uint32) == np.float32(rc).view(np.uint32) and np.float32(s_).view(np.uint32) == np.float32(rs).view(np.uint32), (pos, j, c, rc, s_, rs)

@@ -692,6 +692,50 @@ def test_vision_tower_with_q4_and_unquantised_sections(L, q, n_layers, num_crops
     assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"vision tower q_type {q}, {n_layers - 1} layer(s), {num_crops} crop(s)")
 
 
+def test_image_path_with_five_crops(L):
+    """A 2 x 2 grid of sub-images + the global crop (num_crops = 5, the shape chat.rs produces for a large square image): tower (a few
+    layers) -> projector, (2*12) * (2*12 + 1) + 12 * 13 + 1 = 757 embeddings, bit-equal to the CPU path."""
+    from tools import synth_vision as V
+    cfg = V.VisionCfg(n_layers=3)
+    vsec = V.build_vision_section(cfg, seed=51); psec = V.build_processor_section(seed=52)
+    vis = L.VisionTransformer(vsec); vis_o = O.VisionOracle(vsec)
+    proc = L.PHI3VProcessor(psec); proc_o = O.ProcessorOracle(psec)
+    pv = V.pixel_values(cfg, 5, seed=9)
+    feats = vis.forward(pv, 5); feats_o = vis_o.forward(pv, 5)
+    assert_bit_equal(feats.reshape(-1), feats_o.reshape(-1), "vision tower, 5 crops")
+    got = proc.forward(feats, 576 * 1024, 12, 2, 2); ref = proc_o.forward(feats_o, 576 * 1024, 12, 2, 2)
+    assert got.shape == ref.shape == (757, 3072)
+    assert_bit_equal(got.reshape(-1), ref.reshape(-1), "image projector, 2 x 2 sub-images")
+
+
+def test_contexts_release_their_device_memory(L):
+    """Twenty rounds of create / run / destroy of a text model, a tower and a projector leave the device's free memory where it was
+    (the arena, the prefill buffers, the split-attention scratch, the vision work buffers all go with their owner)."""
+    import ctypes
+    from tools import synth_vision as V
+    hip = ctypes.CDLL("libamdhip64.so")
+    def free_bytes():
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+    img = S.build_image("mini-llama", S.Q8_0, seed=5)
+    vsec = V.build_vision_section(V.VisionCfg(n_layers=2), seed=6); psec = V.build_processor_section(seed=7)
+    toks = S.prompt_tokens("mini-llama", 40, 5)
+    def one_round():
+        m = L.Transformer(img)
+        e = m.get_embeddings(toks); m.fill_kv_cache(e, 0); m.generate_greedy(toks[:4], 4, start_pos=40)
+        v = L.VisionTransformer(vsec); p = L.PHI3VProcessor(psec)
+        f = v.forward(V.pixel_values(V.VisionCfg(n_layers=2), 1, seed=1), 1)
+        p.forward(np.concatenate([f, f]), 576 * 1024, 12, 1, 1)
+        m.close(); v.close(); p.close()
+    one_round(); one_round()                       # (the first rounds may grow runtime-internal pools)
+    before = free_bytes()
+    for _ in range(20):
+        one_round()
+    after = free_bytes()
+    assert before - after < 64 << 20, f"device memory shrank by {(before - after) >> 20} MiB over 20 create / destroy rounds"
+
+
 def test_vision_tower_at_full_depth(L):
     """The tower as configs[4] runs it: 24 layers in the file, 23 executed (vision.rs:303), global crop + one sub-image."""
     from tools import synth_vision as V

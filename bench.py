@@ -86,6 +86,17 @@ def pmc_traffic(model, qtype):
     return None
 
 
+def shard_description(lmrs_amd, model, world, transport):
+    """Which matrices the library split for this model and world size (lmrs_shard_plan: it row-splits the layers' matrices only when
+    the stream a shard stops reading outweighs two exchanges per layer; below that every GPU runs the layers whole and only the
+    classifier's rows are split - DESIGN.md section 6)."""
+    plan = lmrs_amd.shard_plan(model.args, 0, world)
+    if plan["q_heads"][1] == model.args.n_heads:
+        return (f"cls{world}: every GPU runs the layers whole (no exchange inside a layer), the classifier's rows are split over {world} GPUs, "
+                f"one exchange of argmax partials per token by {transport}")
+    return f"tp{world}: rows of every weight matrix split over {world} GPUs, slices exchanged by {transport}"
+
+
 def max_over_ranks(dist, seconds, device=None):
     """The contract's timing rule: the step time of the job is the slowest rank's."""
     if dist is None:
@@ -332,7 +343,7 @@ def main():
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine" if args.qtype == "q8_0" else "int4xint4->int32, f32 combine", "data": "synthetic",
             "config": {"workload": f"{cfg.name} {args.qtype.upper()} (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
-                       "parallelism": "single GPU" if world == 1 else f"tp{world}: rows of every weight matrix split over {world} GPUs, slices exchanged by {transport}",
+                       "parallelism": "single GPU" if world == 1 else shard_description(lmrs_amd, model, world, transport),
                        "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "prefill": prefill,
         }

@@ -76,7 +76,12 @@ int lmrs_p2p_connect(lmrs_ctx* ctx, const void* handles);
 
 /* Host-only: the row ranges shard `rank` of `world` owns.  plan[0..9] = q-head first,count; kv-head first,count;
  * wo/w2 row first,count; gate/up pair first,count; classifier row first,count.  wo and w2 are replicated by default
- * (every shard: first 0, count dim - no gather after them); LMRS_SHARD_SPLIT_OUT=1 row-splits them as well. */
+ * (every shard: first 0, count dim - no gather after them); LMRS_SHARD_SPLIT_OUT=1 row-splits them as well.
+ * Which matrices are split at all depends on the model and the world size: when the gate / up / down bytes a shard would stop reading
+ * (3 * dim * hidden_dim * (1 - 1/world), quantised) are under ~57 MB per layer - two latency-bound exchanges per layer cost more than
+ * that streams - the plan is "cls": heads, rows and pairs are all of them on every shard (the layers run whole, no exchange inside
+ * them) and only the classifier rows are split: one exchange of argmax partials per token.  LMRS_SHARD_PLAN=tp|cls overrides.  (The
+ * 1B / 2B models: cls at every world size; 3B / 3.8B: cls up to 4 GPUs; 8B and larger: tp.)  lmrs_create_sharded follows this plan. */
 int lmrs_shard_plan(const lmrs_args* args, int rank, int world, int* plan10);
 /* 1: the sharded step is one captured hipGraph (RCCL inside); 0: enqueued call by call; -1: not an RCCL shard.  No reference counterpart. */
 int lmrs_shard_uses_graph(const lmrs_ctx* ctx);

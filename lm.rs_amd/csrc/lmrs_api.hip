@@ -87,6 +87,7 @@ struct lmrs_ctx {
     int dim_l = 0, hid_l = 0, voc_l = 0;           // rows of wo/w2, gate-up pairs of w13, classifier rows owned here
     int d0 = 0, h0 = 0, v0 = 0, a0 = 0;            // first owned row / pair / vocab row / att column
     bool rep_out = true;                           // wo / w2 replicated (all dim rows on every shard): no gather after them
+    bool cls_only = false;                         // shard plan "cls": the layers run whole on every shard, only the classifier's rows are split
     ncclComm_t comm = nullptr;                     // RCCL communicator (one process per GPU); null in group mode
     bool eager = false;                            // sharded step could not be captured: enqueue it every call
     float* part = nullptr;                         // [world][values(cls_grid) | indices(cls_grid)] argmax partials
@@ -338,6 +339,19 @@ int enqueue_step(lmrs_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 struct ExchangeDesc { char* buf; size_t bytes, stride; const float* qsrc; size_t qn; };   // bytes valid per shard, blocks `stride` bytes apart (in place); qsrc: f32 slice still to be quantised into this shard's block
 static bool shard_split_out() { static const bool v = getenv("LMRS_SHARD_SPLIT_OUT") != nullptr; return v; }
+// Which matrices to split over `world` GPUs.  Row-splitting a layer's matrices costs two exchanges per layer (four in the fully split
+// form): pure latency, a few microseconds each, every layer of every token.  It pays only when the gate / up / down stream a shard no
+// longer reads is longer than that: (w1 + w3 + w2 bytes per layer) x (1 - 1/world) at the ~6.3 TB/s a GPU streams, against ~9 us for two
+// exchanges - about 57 MB.  Below that (the 1B and 2B models at any world size, the 3B / 3.8B ones at 2 and 4) the plan is "cls": every shard
+// runs the layers whole, with the fused single-GPU kernels and no exchange, and only the classifier - the one big stream of the step,
+// 270 MB for Llama-3.2 - is row-split, for ONE exchange of the argmax partials per token.  LMRS_SHARD_PLAN=tp|cls overrides.
+static bool shard_plan_cls_only(const lmrs_args& a, int world) {
+    if (world <= 1) return false;
+    if (const char* e = getenv("LMRS_SHARD_PLAN")) return !strcmp(e, "cls");
+    const double bpe = a.q_type == LMRS_Q4_0 ? 0.5 + 4.0 / 128 : 1.0 + 4.0 / 128;
+    const double mlp_bytes = 3.0 * a.dim * a.hidden_dim * bpe;
+    return mlp_bytes * (1.0 - 1.0 / world) < 57e6;
+}
 
 int n_segments(const lmrs_ctx* c) { return 4 * (int)c->args.n_layers + 2; }
 
@@ -345,6 +359,7 @@ ExchangeDesc exchange_after(lmrs_ctx* c, int seg) {
     const int L4 = 4 * (int)c->args.n_layers;
     const ExchangeDesc none{nullptr, 0, 0, nullptr, 0};
     auto f32s = [](float* p, size_t count) { return ExchangeDesc{reinterpret_cast<char*>(p), count * 4, count * 4, nullptr, 0}; };
+    if (c->cls_only && seg < L4) return none;                     // plan "cls": nothing is exchanged inside the layers
     if (seg < L4) {
         switch (seg & 3) {
             case 0: return c->qpay ? ExchangeDesc{c->gq_att, (size_t)c->att_dim + (size_t)c->att_dim / 32, c->blk_att, c->p2p ? c->att_out + c->a0 : nullptr, (size_t)c->att_dim} : f32s(c->att_out, (size_t)c->att_dim);
@@ -360,6 +375,8 @@ ExchangeDesc exchange_after(lmrs_ctx* c, int seg) {
 int run_segment(lmrs_ctx* c, int seg) {
     const lmrs_args& a = c->args;
     const int L4 = 4 * (int)a.n_layers;
+    // plan "cls": a layer is the five fused launches of the single-GPU step (its first segment runs all of it)
+    if (c->cls_only && seg < L4) return (seg & 3) == 0 ? enqueue_layer(c, seg >> 2) : 0;
     const bool gemma = a.model_type == LMRS_GEMMA;
     GemvArgs g{};
     g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = gemma; g.st = c->st;
@@ -427,7 +444,7 @@ int run_segment(lmrs_ctx* c, int seg) {
         return 0;
     }
     if (seg == L4) {
-        if (pending_update(c->layers[a.n_layers - 1].rms_post_ffn)) return -1;
+        if (!c->cls_only && pending_update(c->layers[a.n_layers - 1].rms_post_ffn)) return -1;      // ("cls": the layer finished its own residual)
         GemvArgs k = cls_args(c);
         set_launch_tag(5);
         HIP_OK(launch_gemv(k, PRO_RMS_QUANT, EPI_CLS, c->stream));
@@ -460,7 +477,8 @@ int enqueue_step_sharded(lmrs_ctx* c, bool layers_only = false) {
     }
     if (layers_only) {          // the last layer's residual update, so that x holds the finished residual stream; advance the position
         const lmrs_args& a = c->args;
-        if (a.model_type == LMRS_GEMMA) HIP_OK(launch_addnorm(c->x, c->tmp, c->layers[a.n_layers - 1].rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));
+        if (c->cls_only) {}                                        // (whole layers: x is already the finished residual)
+        else if (a.model_type == LMRS_GEMMA) HIP_OK(launch_addnorm(c->x, c->tmp, c->layers[a.n_layers - 1].rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));
         else if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
         hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
     }
@@ -576,6 +594,13 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
 // wo/w2 row first/count, gate-up pair first/count, classifier row first/count.  <0 if `world` does not divide the model.
 extern "C" int lmrs_shard_plan(const lmrs_args* a, int rank, int world, int* plan) {
     if (!a || !plan || world < 1 || rank < 0 || rank >= world) return fail("bad argument");
+    if (shard_plan_cls_only(*a, world)) {                     // the layers whole on every shard, the classifier's rows split
+        if (a->vocab_size % world) return fail("world must divide vocab_size");
+        const int vl = a->vocab_size / world;
+        const int p[10] = {0, (int)a->n_heads, 0, (int)a->n_kv_heads, 0, (int)a->dim, 0, (int)a->hidden_dim, rank * vl, vl};
+        memcpy(plan, p, sizeof p);
+        return 0;
+    }
     if (a->n_kv_heads % world || a->dim % world || a->hidden_dim % world || a->vocab_size % world)
         return fail("world must divide n_kv_heads, dim, hidden_dim and vocab_size");
     const bool rep = !shard_split_out();                      // wo / w2 rows: replicated on every shard by default
@@ -736,17 +761,19 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
 
     // ---- shard plan: whole heads / rows per shard, equal sizes (in-place all-gathers need equal counts)
     const size_t W = (size_t)world;
-    if (world > 1 && (a.n_kv_heads % W || dim % W || hid % W || V % W))
-        return fail("world must divide n_kv_heads, dim, hidden_dim and vocab_size");
+    const bool cls_only = !f32w && shard_plan_cls_only(a, world);
+    if (cls_only ? V % W != 0 : world > 1 && (a.n_kv_heads % W || dim % W || hid % W || V % W))
+        return fail(cls_only ? "world must divide vocab_size" : "world must divide n_kv_heads, dim, hidden_dim and vocab_size");
     if (a.vocab_size / (uint32_t)world < 4) return fail("vocab_size / world must be at least 4");
     const size_t hs = a.head_size;
     // wo and w2 (the projections back to the residual stream) are REPLICATED by default: every shard computes all dim rows
     // from the gathered att_out / h, so the residual needs no gather of its own - two all-gathers per layer instead of four,
     // for 4 + 17 MB of extra weight reads per layer and shard (1-3 us) against two ~10-20 us latency-bound collectives.
     // LMRS_SHARD_SPLIT_OUT=1 restores the fully row-split form.
-    const bool rep_out = !shard_split_out();
-    const size_t att_l = att / W, kv_l = kv / W, dim_l = rep_out ? dim : dim / W, hid_l = hid / W, voc_l = V / W;
-    const size_t a0 = rank * att_l, k0 = rank * kv_l, d0 = rep_out ? 0 : rank * dim_l, h0 = rank * hid_l, v0 = rank * voc_l;
+    const bool rep_out = cls_only || !shard_split_out();
+    const size_t WL = cls_only ? 1 : W;                                 // the layers' split ("cls": none)
+    const size_t att_l = att / WL, kv_l = kv / WL, dim_l = rep_out ? dim : dim / W, hid_l = hid / WL, voc_l = V / W;
+    const size_t a0 = cls_only ? 0 : rank * att_l, k0 = cls_only ? 0 : rank * kv_l, d0 = rep_out ? 0 : rank * dim_l, h0 = cls_only ? 0 : rank * hid_l, v0 = rank * voc_l;
     (void)hs;
 
     lmrs_ctx* c = new lmrs_ctx();
@@ -754,7 +781,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     c->rank = rank; c->world = world; c->att_full = (int)att;
     c->att_dim = (int)att_l; c->kv_dim = (int)kv_l; c->dim_l = (int)dim_l; c->hid_l = (int)hid_l; c->voc_l = (int)voc_l;
     c->a0 = (int)a0; c->d0 = (int)d0; c->h0 = (int)h0; c->v0 = (int)v0;
-    c->rep_out = rep_out;
+    c->rep_out = rep_out; c->cls_only = cls_only;
     const bool sharded = world > 1 || uid != nullptr;
     // transport of the exchanges: RCCL when a communicator id is given; otherwise peer-to-peer pushes (separate processes
     // connect through lmrs_p2p_handles / lmrs_p2p_connect; a lock-step group on one device uses plain copies unless LMRS_GROUP_P2P=1)
@@ -792,7 +819,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     need(dim * 4); need(att_l * 4); need(kv_l * 4); need(att * 4); need(hid * 4); need(V * 4); need(dim * 4); need(dim * 4);
     need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4); need(W * 2 * kMaxArgmaxParts * 4);
     // quantised exchange payloads (Q8_0, whole 128-groups per shard): one padded block per shard
-    c->qpay = sharded && !c->q4 && att_l % 128 == 0 && hid_l % 128 == 0 && !getenv("LMRS_SHARD_F32_PAYLOAD");
+    c->qpay = sharded && !cls_only && !c->q4 && att_l % 128 == 0 && hid_l % 128 == 0 && !getenv("LMRS_SHARD_F32_PAYLOAD");
     c->blk_att = pad256(att_l + att_l / 32); c->blk_h = pad256(hid_l + hid_l / 32);
     need(W * c->blk_att); need(W * c->blk_h);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
@@ -874,6 +901,9 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         c->gq_att = c->xarena + o_gqa; c->gq_h = c->xarena + o_gqh;
         c->xflags = reinterpret_cast<unsigned*>(c->xarena + o_flags); c->xseq = reinterpret_cast<unsigned*>(c->xarena + o_seq); c->xerr = reinterpret_cast<int*>(c->xarena + o_err);
         c->peer_base[rank] = c->xarena;
+        if (cls_only) {   // no peer ever writes the layers' activations: they belong in ordinary (L2-cached) memory; only the partials and logits are exchanged
+            c->att_out = c->alloc<float>(att); c->h = c->alloc<float>(hid); c->tmp = c->alloc<float>(dim);
+        }
     } else {
         c->att_out = c->alloc<float>(att); c->h = c->alloc<float>(hid); c->logits = c->alloc<float>(V); c->tmp = c->alloc<float>(dim);
         c->part = c->alloc<float>(W * 2 * kMaxArgmaxParts);

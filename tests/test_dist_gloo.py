@@ -33,7 +33,8 @@ def _worker(rank, world, port, q):
         assert uid == bytes(range(128))
         assert bench.max_over_ranks(dist, 1.0 + rank) == float(world)
 
-        # 2. shard plan + gather order on a real projection shape (wo of mini-llama: 2048 x 2048)
+        # 2. shard plan + gather order on a real projection shape (wo of mini-llama: 2048 x 2048), row-split plan
+        os.environ["LMRS_SHARD_PLAN"] = "tp"
         cfg = S.CONFIGS["mini-llama"]
         a = lmrs_amd.TransformerArgs()
         a.dim, a.hidden_dim, a.n_heads, a.n_kv_heads, a.head_size, a.vocab_size = cfg.dim, cfg.hidden_dim, cfg.n_heads, cfg.n_kv_heads, cfg.head_size, cfg.vocab_size
@@ -59,6 +60,22 @@ def _worker(rank, world, port, q):
         # q heads stay with their kv head (kv_mul q heads per kv head)
         kv_mul = cfg.n_heads // cfg.n_kv_heads
         assert plan["q_heads"][0] == plan["kv_heads"][0] * kv_mul and plan["q_heads"][1] == plan["kv_heads"][1] * kv_mul
+        # 3. the other plan ("cls", what the library picks by itself for a model this small): whole layers on every shard, the
+        #    classifier's rows split - and the gathered argmax partials give the unsharded answer
+        os.environ["LMRS_SHARD_PLAN"] = "cls"
+        pc = lmrs_amd.shard_plan(a, rank, world)
+        assert pc["q_heads"] == (0, cfg.n_heads) and pc["kv_heads"] == (0, cfg.n_kv_heads) and pc["hidden_pairs"] == (0, cfg.hidden_dim) and pc["dim_rows"] == (0, cfg.dim)
+        assert pc["vocab_rows"] == (rank * (cfg.vocab_size // world), cfg.vocab_size // world)
+        del os.environ["LMRS_SHARD_PLAN"]
+        assert lmrs_amd.shard_plan(a, rank, world) == pc          # the default for this geometry
+        V0, VL = pc["vocab_rows"]
+        logits = rng.standard_normal(cfg.vocab_size).astype(np.float32)              # same on every rank
+        loc = int(np.argmax(logits[V0:V0 + VL]))
+        mine_best = torch.tensor([float(logits[V0 + loc]), float(V0 + loc)], dtype=torch.float64)
+        allb = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allb, mine_best)
+        best = max(allb, key=lambda t_: (float(t_[0]), -float(t_[1])))
+        assert int(best[1]) == int(np.argmax(logits))
         dist.destroy_process_group()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
@@ -78,8 +95,9 @@ def test_two_rank_gloo_plumbing_and_shard_plan():
     assert all(r[1] == "ok" for r in res), res
 
 
-def test_shard_plan_rejects_indivisible_worlds():
+def test_shard_plan_rejects_indivisible_worlds(monkeypatch):
     import lmrs_amd
+    monkeypatch.setenv("LMRS_SHARD_PLAN", "tp")
     a = lmrs_amd.TransformerArgs()
     a.dim, a.hidden_dim, a.n_heads, a.n_kv_heads, a.head_size, a.vocab_size = 2048, 8192, 32, 8, 64, 128256
     for w in (1, 2, 4, 8):
@@ -88,3 +106,11 @@ def test_shard_plan_rejects_indivisible_worlds():
         lmrs_amd.shard_plan(a, 0, 3)
     with pytest.raises(lmrs_amd.LmrsError):
         lmrs_amd.shard_plan(a, 0, 16)            # 8 kv heads
+    monkeypatch.setenv("LMRS_SHARD_PLAN", "cls")                                  # whole layers, classifier split: only the vocabulary counts
+    assert lmrs_amd.shard_plan(a, 2, 3)["vocab_rows"] == (2 * 42752, 42752) and lmrs_amd.shard_plan(a, 0, 16)["q_heads"] == (0, 32)
+    with pytest.raises(lmrs_amd.LmrsError):
+        lmrs_amd.shard_plan(a, 0, 5)
+    monkeypatch.delenv("LMRS_SHARD_PLAN")                                         # the default: by the bytes a shard stops reading
+    assert lmrs_amd.shard_plan(a, 0, 8)["q_heads"] == (0, 32)                     # Llama-3.2-1B: the classifier only, at any world size
+    a.dim, a.hidden_dim, a.n_heads, a.head_size = 4096, 14336, 32, 128           # Llama-3.1-8B: the layers' matrices are split
+    assert lmrs_amd.shard_plan(a, 0, 2)["q_heads"] == (0, 16)

@@ -492,7 +492,8 @@ def test_split_attention_for_long_contexts(L, monkeypatch, cfg, q, n_steps, spli
     ("mini-llama", S.Q8_0, 4, "f32"), ("mini-llama", S.Q8_0, 4, "split"), ("mini-llama3b", S.Q8_0, 8, "split"),
     ("mini-gemma", S.Q8_0, 2, "int8"), ("mini-gemma", S.Q8_0, 4, "split"), ("mini-gemma", S.Q4_0, 4, "int8"), ("mini-llama", S.Q4_0, 4, "int8"),
     ("mini-llama", S.Q8_0, 2, "p2p"), ("mini-llama3b", S.Q8_0, 2, "p2p"), ("mini-gemma", S.Q8_0, 2, "p2p-split"),
-    ("mini-llama-v4102", S.Q8_0, 2, "int8")])
+    ("mini-llama-v4102", S.Q8_0, 2, "int8"),
+    ("mini-llama", S.Q8_0, 2, "cls"), ("mini-llama", S.Q8_0, 8, "cls"), ("mini-gemma", S.Q4_0, 4, "cls"), ("mini-phi", S.Q8_0, 2, "cls-p2p"), ("mini-llama-v4102", S.Q8_0, 2, "cls")])
 def test_row_sharding_is_bit_identical(L, monkeypatch, cfg, q, world, mode):
     """`world` logical shards on ONE device - same kernels, same partition as the multi-GPU path: every logit must equal the unsharded
     CPU path bit for bit.  int8: att_out / h travel quantised by their producers (Q8_0; Q4_0 models fall back to f32 slices);
@@ -501,6 +502,9 @@ def test_row_sharding_is_bit_identical(L, monkeypatch, cfg, q, world, mode):
     the peers' arenas + flags) instead of lock-step copies (two shards only: a process has four hardware queues by default, and
     with more shards in ONE process two of them share a queue - the second's kernels would sit behind the first's waiting exchange
     kernel; separate processes, the real launch shape, each have their own: test_peer_to_peer_shards_in_separate_processes)."""
+    # cls: the layers whole on every shard, only the classifier's rows split (the plan the library picks by itself for models this small;
+    # every other mode pins the row-split plan)
+    monkeypatch.setenv("LMRS_SHARD_PLAN", "cls" if mode.startswith("cls") else "tp")
     if mode == "f32": monkeypatch.setenv("LMRS_SHARD_F32_PAYLOAD", "1")
     if "split" in mode: monkeypatch.setenv("LMRS_SHARD_SPLIT_OUT", "1")
     if "p2p" in mode: monkeypatch.setenv("LMRS_GROUP_P2P", "1")
@@ -530,6 +534,7 @@ def test_row_sharding_on_random_geometries(L, monkeypatch, i):
         if cfg.n_kv_heads == 2:
             break
     cfg = dataclasses.replace(cfg, vocab_size=cfg.vocab_size + cfg.vocab_size % 2)           # the world must divide the vocabulary
+    monkeypatch.setenv("LMRS_SHARD_PLAN", "tp" if i < 6 else "cls")
     if i % 2: monkeypatch.setenv("LMRS_SHARD_SPLIT_OUT", "1")
     q = [S.Q8_0, S.Q4_0][(i // 2) % 2]
     img = S.build_image(cfg, q, seed=90 + i, threads=1)
@@ -570,17 +575,19 @@ def _p2p_rank(rank, world, img_path, cfg, env, q_in, q_out):
         q_out.put((rank, "error", traceback.format_exc()))
 
 
-@pytest.mark.parametrize("cfg,world", [("mini-llama", 2), ("mini-gemma", 2), ("mini-llama3b", 4)])
-def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world):
+@pytest.mark.parametrize("cfg,world,plan", [("mini-llama", 2, "tp"), ("mini-gemma", 2, "tp"), ("mini-llama3b", 4, "tp"), ("mini-llama", 4, "cls"), ("mini-gemma", 2, "cls")])
+def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan):
     """The multi-GPU launch shape on a one-GPU box: `world` PROCESSES, one shard each (here all on device 0), exchange arenas opened
     through IPC handles, every exchange a push kernel that really waits for the other process's flag.  fill_kv_cache on the shards,
-    greedy decoding across the split-attention switch, full logits on every rank - all bit-equal to the CPU path."""
+    greedy decoding across the split-attention switch, full logits on every rank - all bit-equal to the CPU path.  plan "tp": the
+    layers' matrices row-split (exchanges inside every layer); "cls": whole layers on every shard, the classifier split (one exchange
+    per token)."""
     import multiprocessing as mp
     img = S.build_image(cfg, S.Q8_0, seed=43)
     path = str(tmp_path / "m.lmrs"); img.tofile(path)
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue(); q_in = [ctx.Queue() for _ in range(world)]
-    env = {"LMRS_ATT_SPLIT_POS": "16", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LMRS_P2P_TIMEOUT_MS": "1500"}
+    env = {"LMRS_ATT_SPLIT_POS": "16", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LMRS_P2P_TIMEOUT_MS": "1500", "LMRS_SHARD_PLAN": plan}
     procs = [ctx.Process(target=_p2p_rank, args=(r, world, path, cfg, env, q_in[r], q_out)) for r in range(world)]
     for p in procs: p.start()
     try:

@@ -1095,7 +1095,9 @@ constexpr int kPrefillTokens = 512;
 static bool prefill_batched_ok(const lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     if (getenv("LMRS_NO_BATCHED_PREFILL")) return false;
-    if ((a.q_type != LMRS_Q8_0 && a.q_type != LMRS_Q4_0) || c->world > 1 || c->comm || !c->g_layers) return false;
+    // (a "cls" shard runs the layers whole: the batched path applies to it as to a single GPU, every shard filling its own cache)
+    const bool whole_layers = c->cls_only || (c->world == 1 && !c->comm && c->g_layers);
+    if ((a.q_type != LMRS_Q8_0 && a.q_type != LMRS_Q4_0) || !whole_layers) return false;
     if (!rows_prologue_supported((int)a.dim) || !rows_prologue_supported(c->att_dim) || !rows_prologue_supported((int)a.hidden_dim)) return false;
     if (a.model_type == LMRS_GEMMA) { if (a.head_size != 256 || a.dim != 2304) return false; }
     else if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
@@ -1182,7 +1184,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
     if (!c || !embeddings) return fail("NULL argument");
     if ((size_t)curr_pos + n > c->args.seq_len) return fail("positions out of range");
     HIP_OK(hipSetDevice(c->device));
-    if (!c->g_layers) {
+    if (!c->g_layers && !(c->cls_only && n > 1 && prefill_batched_ok(c))) {
         // Row-sharded context: forward_layer(sl = n) is, value for value, n single-token passes through the layers; each token goes
         // through the sharded layer segments (exchanges included), every shard ends with the whole residual stream in x.
         if (!(c->comm || (c->p2p && c->p2p_ready))) return fail("fill_kv_cache: this sharded context has no transport (lock-step groups are driven by lmrs_group_forward)");

@@ -97,8 +97,15 @@ struct lmrs_ctx {
     // a shard pushes its block straight into its peers' copies (xGMI stores) and raises a flag there (exchange_push_kernel)
     bool p2p = false, p2p_ready = false; char* xarena = nullptr; size_t xarena_bytes = 0; char* peer_base[8] = {};
     unsigned *xflags = nullptr, *xseq = nullptr; int* xerr = nullptr; int ex_slot = 0; bool xarena_is_ipc[8] = {};
-    // ---- fused attention block (qkv -> attention -> wo in one launch, in-launch arrival counters)
-    int fused_cls = 0; unsigned* flags = nullptr; int n_flag_words = 0; int* err = nullptr; int* h_err = nullptr;
+    int* err = nullptr; int* h_err = nullptr;      // error word of the bounded in-launch waits (merged qkv + attention launch, classifier tail)
+    // ---- merged qkv + attention launch (launch_qkv_attn): per-layer {value, tag} granules, the step sequence number the tags are
+    // made of (bumped by the last kernel of every step, never reset), and the graph of the separate kernels for the steps it does not cover
+    // qa_mode (what enqueue_layer launches): 0 the separate kernels, 1 merged with one workgroup per head (pos < qa_max_T), 2 merged with one
+    // wave per head (pos < qa_wave_T).  g_step is the graph of the best mode; g_step_alt[m] the others, captured on first use.
+    bool qkv_att = false; int qa_mode = 0; unsigned long long* gran = nullptr; unsigned* seq = nullptr; int qa_max_T = 0, qa_wave_T = 0;
+    hipGraphExec_t g_step_alt[3] = {nullptr, nullptr, nullptr};
+    // ---- final argmax folded into the classifier launch (ClsTail): packed partials
+    bool cls_tail = false; unsigned long long* part_pk = nullptr;
 
     template <class T> T* alloc(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -109,9 +116,16 @@ struct lmrs_ctx {
 
 namespace {
 
-__global__ void advance_pos_kernel(DevState* st) { st->pos += 1; st->step_count += 1; }
+__global__ void advance_pos_kernel(DevState* st, unsigned* seq) { st->pos += 1; st->step_count += 1; *seq += 1u; }
 
 size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// how a step at position `pos` runs qkv + attention (lmrs_ctx::qa_mode)
+int qa_mode_for(const lmrs_ctx* c, uint32_t pos) {
+    if (!c->qkv_att) return 0;
+    if ((int)pos < c->qa_wave_T) return 2;
+    return (int)pos < c->qa_max_T ? 1 : 0;
+}
 
 // RoPE terms, transformer.rs:446-482 (libm powf/cosf/sinf/logf exactly where the reference calls them).
 void rope_terms(const lmrs_args& a, uint32_t p, uint32_t j, float* fcr, float* fci) {
@@ -199,15 +213,6 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     GemvArgs g{};
     g.q4 = c->q4; g.eps = a.rms_norm_eps; g.add_unit = gemma; g.st = c->st;
     g.att_dim = c->att_dim; g.kv_dim = c->kv_dim; g.seq_len = a.seq_len; g.layer = l;
-    if (c->fused_cls) {
-        // 1-3 in one launch: qkv -> RoPE + attention -> wo, separated by in-launch arrival counters (lmrs_fused.inc)
-        FusedAttnArgs f{};
-        f.wqkv = static_cast<const int8_t*>(L.wqkv); f.wo = static_cast<const int8_t*>(L.wo); f.sqkv = L.sqkv; f.so = L.so; f.rms_att = L.rms_att;
-        f.eps = a.rms_norm_eps; f.x = c->x; f.q = c->q; f.k_raw = c->k_raw; f.att_out = c->att_out; f.k_cache = c->k_cache; f.v_cache = c->v_cache;
-        f.rope = c->rope; f.seq_len = a.seq_len; f.layer = l; f.flags = c->flags + (size_t)l * kFusedFlagWordsPerLayer; f.err = c->err; f.st = c->st;
-        f.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-        HIP_OK(launch_fused_attn(c->fused_cls, f, a.head_size, c->stream));
-    } else {
     // 1. rmsnorm + quantize | Wqkv | q, raw k, v -> cache            (:409-431)
     g.wq = L.wqkv; g.ws = L.sqkv; g.n = a.dim; g.o = c->att_dim + 2 * c->kv_dim;
     g.xin = c->x; g.rms_w = L.rms_att; g.out = c->q; g.k_raw = c->k_raw; g.v_cache = c->v_cache;
@@ -218,17 +223,25 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     // layer's "x += rmsnorm(ffn_out, post_ffn)" (:643-650) is still pending in (x2, tmp): this prologue applies it, x2 -> x.
     const bool pending = c->gemma_fused && l > 0;
     if (pending) { g.xin = c->x2; g.delta = c->tmp; g.add_w = c->layers[l - 1].rms_post_ffn; g.xout = c->x; }
-    HIP_OK(launch_gemv(g, pending ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_QKV, c->stream));
-    g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
-    // 2. RoPE + attention                                               (:443-544)
     AttnArgs t{};
     t.q = c->q; t.k_raw = c->k_raw; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->att_out;
     t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.seq_len = a.seq_len; t.layer = l;
     t.gemma = gemma; t.st = c->st;
+    if (c->qa_mode && !c->att_split_chunks) {
+        // 1 + 2 as ONE launch: the attention workgroups poll the granules the qkv workgroups write (launch_qkv_attn)
+        g.gran = c->gran + (size_t)l * (c->att_dim + 2 * c->kv_dim); g.seq = c->seq;
+        t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+        HIP_OK(launch_qkv_attn(g, pending ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, t, c->err, c->qa_max_T, c->qa_mode == 2, c->stream));
+        g.gran = nullptr; g.seq = nullptr;
+    } else {
+    HIP_OK(launch_gemv(g, pending ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_QKV, c->stream));
+    // 2. RoPE + attention                                               (:443-544)
     t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     set_launch_tag(1);
     if (c->att_split_chunks) HIP_OK(launch_attention_split(t, c->att_S, c->att_split_chunks, c->stream));
     else HIP_OK(launch_attention(t, c->stream));
+    }
+    g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
     // 3. quantize | Wo | x += ...                                       (:550-576)
     g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -236,7 +249,6 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
     set_launch_tag(7);
     if (gemma && !c->gemma_fused) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
-    }
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
     g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -310,11 +322,16 @@ int enqueue_step(lmrs_ctx* c) {
     GemvArgs g = cls_args(c);                                   // final rmsnorm + quantize | classifier | argmax partials (:341-381)
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     set_launch_tag(5);
+    ArgmaxArgs m{};
+    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tail_row = unwritten_tail(c); m.tokens = c->tokens; m.st = c->st; m.seq = c->seq; m.emb = embed_args(c);
+    if (c->cls_tail) {                                          // one GPU: the classifier's last-arriving workgroup finishes the step itself
+        g.has_tail = 1; g.tail.part_pk = c->part_pk; g.tail.err = c->err; g.tail.m = m;
+        HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
+        return 0;
+    }
     if (c->f32) HIP_OK(launch_gemv_f32(g, PRO_RMS_QUANT, EPI_CLS, c->stream));
     else HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
     set_launch_tag(6);
-    ArgmaxArgs m{};
-    m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tail_row = unwritten_tail(c); m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.flags = c->flags; m.n_flag_words = c->n_flag_words;
     m.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
@@ -454,7 +471,7 @@ int run_segment(lmrs_ctx* c, int seg) {
     ArgmaxArgs m{};
     m.part_val = c->part; m.part_idx = reinterpret_cast<const int*>(c->part) + c->cls_grid; m.n_part = c->cls_grid;
     m.n_groups = c->world; m.group_stride = 2 * c->cls_grid;
-    m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.emb = embed_args(c); m.tail_row = unwritten_tail(c);
+    m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.seq = c->seq; m.emb = embed_args(c); m.tail_row = unwritten_tail(c);
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
 }
@@ -480,7 +497,7 @@ int enqueue_step_sharded(lmrs_ctx* c, bool layers_only = false) {
         if (c->cls_only) {}                                        // (whole layers: x is already the finished residual)
         else if (a.model_type == LMRS_GEMMA) HIP_OK(launch_addnorm(c->x, c->tmp, c->layers[a.n_layers - 1].rms_post_ffn, a.dim, a.rms_norm_eps, c->stream));
         else if (!c->rep_out) HIP_OK(launch_addvec(c->x, c->tmp, a.dim, c->stream));
-        hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
+        hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st, c->seq);
     }
     return 0;
 }
@@ -527,7 +544,7 @@ int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out) {
     else {
         for (uint32_t l = 0; l < c->args.n_layers && !rc; ++l) rc = enqueue_layer(c, (int)l);
         if (!rc) rc = enqueue_finish_residual(c);
-        if (!rc) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st);
+        if (!rc) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, c->stream, c->st, c->seq);
     }
     hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return -1; }
@@ -556,10 +573,7 @@ int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end, int win_base = -1)
     DevState* hs = c->h_st + (c->h_st_next++ % kStateSlots);
     hs->pos = (int)pos; hs->prompt_end = (int)prompt_end; hs->step_count = 0; hs->win_base = win_base;
     HIP_OK(hipMemcpyAsync(c->st, hs, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
-    if (c->flags) {       // in-launch arrival counters and error word start every call from zero
-        HIP_OK(hipMemsetAsync(c->flags, 0, (size_t)c->n_flag_words * 4, c->stream));
-        HIP_OK(hipMemsetAsync(c->err, 0, 4, c->stream));
-    }
+    if (c->qkv_att || c->cls_tail) HIP_OK(hipMemsetAsync(c->err, 0, 4, c->stream));                // the error word of the bounded in-launch waits starts every call from zero
     return 0;
 }
 
@@ -570,7 +584,7 @@ int check_err(lmrs_ctx* c) {
         HIP_OK(hipMemcpy(&e, c->xerr, 4, hipMemcpyDeviceToHost));
         if (e) { (void)hipMemset(c->xerr, 0, 4); return fail("peer-to-peer exchange " + std::to_string(e - 1) + " timed out waiting for a peer (results of this call are invalid)"); }
     }
-    if (!c->err) return 0;
+    if (!c->err || !(c->qkv_att || c->cls_tail)) return 0;
     HIP_OK(hipMemcpy(c->h_err, c->err, 4, hipMemcpyDeviceToHost));
     if (*c->h_err) return fail("in-launch synchronisation timed out at stage " + std::to_string(*c->h_err - 1) + " (results of this call are invalid)");
     return 0;
@@ -823,7 +837,8 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     c->blk_att = pad256(att_l + att_l / 32); c->blk_h = pad256(hid_l + hid_l / 32);
     need(W * c->blk_att); need(W * c->blk_h);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
-    c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8); need(nl * kFusedFlagWordsPerLayer * 4 + 512);
+    c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8); need(512);
+    need(nl * (att_l + 2 * kv_l) * 8); need(256); need(256); need(kMaxArgmaxParts * 8); need(256);       // granules of the merged qkv + attention launch, step sequence number, error word
     total += 4096;
     HCK(hipMalloc(reinterpret_cast<void**>(&c->arena), total));
     c->arena_bytes = total;
@@ -910,20 +925,12 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         c->gq_att = c->alloc<char>(W * c->blk_att); c->gq_h = c->alloc<char>(W * c->blk_h);
     }
     c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
+    c->seq = c->alloc<unsigned>(1); c->gran = c->alloc<unsigned long long>(nl * (att_l + 2 * kv_l)); c->err = c->alloc<int>(1);
+    c->part_pk = c->alloc<unsigned long long>(kMaxArgmaxParts);
+    if (!c->seq || !c->gran || !c->err || !c->part_pk) { fail("arena overflow"); return cleanup(); }
+    HCK(hipMemsetAsync(c->part_pk, 0, kMaxArgmaxParts * 8, c->stream));
+    HCK(hipMemsetAsync(c->seq, 0, 4, c->stream)); HCK(hipMemsetAsync(c->gran, 0, nl * (att_l + 2 * kv_l) * 8, c->stream)); HCK(hipMemsetAsync(c->err, 0, 4, c->stream));
     if (getenv("LMRS_DEBUG_TIMELINE")) { c->dbg = c->alloc<unsigned long long>(8 * 1024); if (c->dbg) HCK(hipMemsetAsync(c->dbg, 0, 8 * 1024 * 8, c->stream)); }
-    // Opt-in (LMRS_FUSED=1): measured on MI355X the in-launch arrive/wait edges cost as much as the two kernel boundaries
-    // they replace (15.6 us fused vs 14.9 us as three launches per layer), so the separate launches stay the default.
-    if (!sharded && getenv("LMRS_FUSED")) {
-        const int cls = fused_attn_class((int)dim, (int)a.n_heads, (int)a.n_kv_heads, (int)a.head_size, c->q4, a.model_type != LMRS_GEMMA);
-        int per_cu = 0; hipDeviceProp_t prop;
-        if (cls && fused_attn_prepare(cls, (int)a.head_size, (int)a.seq_len, &per_cu) == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess &&
-            per_cu * prop.multiProcessorCount >= fused_attn_grid(cls)) {      // every workgroup must be resident (they wait on each other)
-            c->n_flag_words = (int)nl * kFusedFlagWordsPerLayer;
-            c->flags = c->alloc<unsigned>(c->n_flag_words); c->err = c->alloc<int>(1);
-            if (c->flags && c->err) c->fused_cls = cls;
-        }
-        (void)hipGetLastError();
-    }
     c->stage = c->alloc<float>(c->stage_floats);
     if (!c->stage) { fail("arena overflow"); return cleanup(); }
     HCK(hipMemsetAsync(c->k_cache, 0, kvn * 4, c->stream)); HCK(hipMemsetAsync(c->v_cache, 0, kvn * 4, c->stream));   // :302-303
@@ -956,11 +963,24 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         GemvArgs g = cls_args(c);
         c->cls_grid = f32w ? gemv_f32_grid(g, EPI_CLS) : gemv_grid(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS);
     }
+    if (!sharded && !f32w && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 0)) {
+        // qkv + attention as one launch (short contexts) when the model's qkv launch has a merged class for every prologue it uses
+        GemvArgs q{}; q.q4 = c->q4; q.n = a.dim; q.o = c->att_dim + 2 * c->kv_dim;
+        AttnArgs t{}; t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.gemma = a.model_type == LMRS_GEMMA;
+        c->qkv_att = qkv_attn_supported(q, PRO_RMS_QUANT, t) && (!c->gemma_fused || qkv_attn_supported(q, PRO_ADD_RMS_QUANT, t)) &&
+                     !(a.model_type == LMRS_GEMMA && !c->gemma_fused);
+        c->qa_max_T = a.seq_len < 1024 ? (int)a.seq_len : 1024;
+        if (c->qkv_att && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 1)) c->qa_wave_T = qkv_attn_wave_T((int)a.head_size);   // LMRS_QKV_ATT=1: workgroup form only
+        if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = 0;                  // (its prefetch reads whole 64-row blocks of the caches)
+    }
+    c->cls_tail = !sharded && !f32w && V < (1u << 20) - 1 && !(getenv("LMRS_CLS_TAIL") && atoi(getenv("LMRS_CLS_TAIL")) == 0);
     if (!sharded) {
+        c->qa_mode = qa_mode_for(c, 0);
         CK(capture(c, true, &c->g_step));
+        c->qa_mode = 0;                         // the layers-only graph serves fill_kv_cache's token-by-token form at ANY position: separate kernels
         CK(capture(c, false, &c->g_layers));
         // from this position on a step uses the split attention (scores by key chunk, V by dim slice): graphs captured on first use
-        if (!c->dbg && !c->fused_cls) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
+        if (!c->dbg) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
     } else if (c->comm) {
         // RCCL collectives inside a captured graph: use it when the runtime accepts it, else enqueue every step
         if (capture(c, true, &c->g_step)) { c->g_step = nullptr; c->eager = true; (void)hipGetLastError(); g_err.clear(); }
@@ -982,6 +1002,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     for (auto& g : c->g_step_long) if (g) (void)hipGraphExecDestroy(g);
     if (c->att_S) (void)hipFree(c->att_S);
     if (c->g_layers) (void)hipGraphExecDestroy(c->g_layers);
+    for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) (void)hipHostFree(c->h_logits);
@@ -1019,6 +1040,17 @@ static int launch_step(lmrs_ctx* c, uint32_t pos) {
                 if (rc) return -1;
             }
             HIP_OK(hipGraphLaunch(c->g_step_long[b], c->stream));
+            return 0;
+        }
+        const int mode = qa_mode_for(c, pos);
+        if (mode != qa_mode_for(c, 0)) {                      // past the context the primary graph's merged launch covers
+            if (!c->g_step_alt[mode]) {
+                c->qa_mode = mode;
+                const int rc = capture(c, true, &c->g_step_alt[mode]);
+                c->qa_mode = 0;
+                if (rc) return -1;
+            }
+            HIP_OK(hipGraphLaunch(c->g_step_alt[mode], c->stream));
             return 0;
         }
         HIP_OK(hipGraphLaunch(c->g_step, c->stream));
@@ -1354,7 +1386,6 @@ extern "C" int lmrs_bench_gemv(lmrs_ctx* c, int iters, double* us5, double* byte
 extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9, double* bytes9, int* count9) {
     if (!c || iters <= 0 || !us9 || !bytes9 || !count9) return fail("bad argument");
     const bool sharded = c->comm || c->p2p;
-    if (c->fused_cls) return fail("lmrs_bench_step: default launch structure only");
     if (sharded ? !(c->comm || c->p2p_ready) : !c->g_step) return fail("lmrs_bench_step: the context cannot run a step by itself");
     if ((size_t)pos + iters + 1 > c->args.seq_len) return fail("positions out of range");
     if (c->att_split_pos > 0 && (int)(pos + iters + 1) > c->att_split_pos) return fail("lmrs_bench_step: positions below the split-attention threshold only");
@@ -1364,7 +1395,9 @@ extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9
     const double bpe = c->q4 ? 0.5 : 1.0, sc = bpe + 4.0 / 128.0, dim = a.dim, att = c->att_dim, kv = c->kv_dim, attf = c->att_full, hidf = a.hidden_dim;
     const double wbytes[9] = {dim * (att + 2 * kv) * sc, 0, attf * c->dim_l * sc, 2.0 * dim * c->hid_l * sc, hidf * c->dim_l * sc, (double)c->voc_l * dim * sc, 0, 0, 0};
     if (set_state(c, pos, 0)) return -1;
-    auto one_step = [&]() -> int { c->ex_slot = 0; return sharded ? enqueue_step_sharded(c) : enqueue_step(c); };
+    const int qmode = qa_mode_for(c, pos + iters);       // the launches of the graph the timed run replayed (the mode of the last position)
+    const bool merged = qmode != 0;
+    auto one_step = [&]() -> int { c->ex_slot = 0; c->qa_mode = qmode; const int r = sharded ? enqueue_step_sharded(c) : enqueue_step(c); c->qa_mode = 0; return r; };
     // dry pass (also the untimed warm-up: the first eager launches pay one-off costs): how many launches does a step have?
     hipEvent_t dummy[2]; int dtag[1];
     HIP_OK(hipEventCreate(&dummy[0])); HIP_OK(hipEventCreate(&dummy[1]));
@@ -1389,7 +1422,8 @@ extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9
             float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
             const int kind = tags[i] >= 0 && tags[i] < 9 ? tags[i] : 7;
             us9[kind] += (double)ms * 1e3; count9[kind] += 1;
-            bytes9[kind] += kind == 1 ? 2.0 * kv * 4 * ((double)pos + it + 3) : wbytes[kind];     // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
+            const double att_bytes = 2.0 * kv * 4 * ((double)pos + it + 3);                       // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
+            bytes9[kind] += kind == 1 ? att_bytes : wbytes[kind] + (kind == 0 && merged ? att_bytes : 0.0);   // merged launch: both under kind 0
         }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -1402,7 +1436,7 @@ extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9
 extern "C" int lmrs_debug_timeline(lmrs_ctx* c, unsigned long long* out, int max_nodes, int* n_nodes) {
     if (!c || !c->dbg) return fail("debug timeline not enabled (set LMRS_DEBUG_TIMELINE=1 before lmrs_create)");
     HIP_OK(hipSetDevice(c->device));
-    const int n = (c->fused_cls ? 3 : 5) * (int)c->args.n_layers + 2;
+    const int n = 5 * (int)c->args.n_layers + (c->cls_tail ? 1 : 2);
     const int m = n < max_nodes ? n : max_nodes;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipMemcpy(out, c->dbg, (size_t)m * 8 * 8, hipMemcpyDeviceToHost));
@@ -1435,7 +1469,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (c->fused_cls ? 3 : 5)) * (int)a.n_layers + 2;
+    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (qa_mode_for(c, pos) && !(c->att_split_pos > 0 && (int)pos >= c->att_split_pos) ? 4 : 5)) * (int)a.n_layers + (c->cls_tail ? 1 : 2);
     return 0;
 }
 
@@ -1556,13 +1590,23 @@ extern "C" int lmrs_op_classifier_argmax(int device, const float* x, const float
     g.wq = dq; g.ws = static_cast<float*>(ds); g.n = (int)n; g.o = (int)o; g.xin = static_cast<float*>(dx); g.rms_w = static_cast<float*>(dw); g.eps = eps;
     g.out = static_cast<float*>(dl); g.part_val = static_cast<float*>(pv); g.part_idx = static_cast<int*>(pi); g.st = static_cast<DevState*>(dst);
     const int grid = gemv_grid(g, PRO_RMS_QUANT, EPI_CLS);
-    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, nullptr));
     ArgmaxArgs m{};
     m.part_val = g.part_val; m.part_idx = g.part_idx; m.n_part = grid; m.n_groups = 1; m.logits = g.out; m.tokens = static_cast<uint32_t*>(dtok); m.st = static_cast<DevState*>(dst);
     m.emb.dim = 0; m.tail_row = 0;                      // no embedding row to prepare; o % 4 == 0
+    // both forms the decode step uses: two launches (row-sharded steps), and the argmax folded into the classifier launch (one GPU);
+    // they must agree - the folded form's answer is returned
+    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, nullptr));
     HIP_OK(launch_argmax_final(m, nullptr));
-    uint32_t tk[2];
+    uint32_t tk[2], tk2[2];
+    HIP_OK(hipMemcpy(tk2, dtok, 8, hipMemcpyDeviceToHost));
+    void *ppk = S.get(kMaxArgmaxParts * 8), *ptk = S.get(16);
+    if (!ptk) return fail("hipMalloc failed");
+    HIP_OK(hipMemset(ppk, 0, kMaxArgmaxParts * 8)); HIP_OK(hipMemset(ptk, 0, 16)); HIP_OK(hipMemset(dtok, 0, 16)); HIP_OK(hipMemset(dst, 0, sizeof(DevState)));
+    g.has_tail = 1; g.tail.part_pk = static_cast<unsigned long long*>(ppk); g.tail.err = static_cast<int*>(ptk) + 1; m.seq = static_cast<unsigned*>(ptk); g.tail.m = m;
+    HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, nullptr));
     HIP_OK(hipMemcpy(tk, dtok, 8, hipMemcpyDeviceToHost));
+    { int e2[2]; HIP_OK(hipMemcpy(e2, ptk, 8, hipMemcpyDeviceToHost)); if (e2[1]) return fail("classifier argmax: the folded form's consumer timed out"); }
+    if (tk[1] != tk2[1]) return fail("classifier argmax: the folded form answered " + std::to_string(tk[1]) + ", the two-launch form " + std::to_string(tk2[1]));
     *token = tk[1];                                     // tokens[pos + 1] with pos = 0, prompt_end = 0
     if (logits) HIP_OK(hipMemcpy(logits, dl, o * 4, hipMemcpyDeviceToHost));
     return 0;

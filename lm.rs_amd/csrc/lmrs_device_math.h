@@ -87,6 +87,28 @@ __device__ __forceinline__ float serial_sum16(float o, const float* p, int n) {
     return o;
 }
 
+// carry + e[lane 0] + e[lane 1] + ... + e[lane 16 * nrows - 1], strictly in lane order, with no LDS traffic: the running sum lives in
+// lane 15 of the current 16-lane row and takes the row's values one by one through the DPP operand of the add itself
+// (v_add_f32_dpp ... row_shr:k fetches lane 15 - k: 16 dependent adds per row and nothing else); row_bcast:15 hands the sum to
+// lane 15 of the next row.  Every lane of the wave must be active; nrows (1..4) wave-uniform.  The result is returned in every lane.
+#define LMRS_DPP_ADD(k) "v_add_f32_dpp %0, %1, %0 row_shr:" #k " row_mask:0xf bank_mask:0xf\n\t"
+#define LMRS_DPP_ROW                                                                                                                  \
+    LMRS_DPP_ADD(15) LMRS_DPP_ADD(14) LMRS_DPP_ADD(13) LMRS_DPP_ADD(12) LMRS_DPP_ADD(11) LMRS_DPP_ADD(10) LMRS_DPP_ADD(9) LMRS_DPP_ADD(8) \
+    LMRS_DPP_ADD(7) LMRS_DPP_ADD(6) LMRS_DPP_ADD(5) LMRS_DPP_ADD(4) LMRS_DPP_ADD(3) LMRS_DPP_ADD(2) LMRS_DPP_ADD(1) "v_add_f32 %0, %1, %0"
+__device__ __forceinline__ float wave_serial_sum(float carry, float e, int nrows) {
+    float acc = carry;
+    // (s_nop 1: a VGPR written by a VALU instruction needs two wait states before a DPP read - inline asm gets no hazard handling)
+    asm volatile("s_nop 1\n\t" LMRS_DPP_ROW : "+v"(acc) : "v"(e));
+    if (nrows > 1) {
+        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 row_bcast:15 row_mask:0x2 bank_mask:0xf\n\t" LMRS_DPP_ROW : "+v"(acc) : "v"(e));
+        if (nrows > 2) {
+            asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 row_bcast:15 row_mask:0x4 bank_mask:0xf\n\t" LMRS_DPP_ROW : "+v"(acc) : "v"(e));
+            if (nrows > 3) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 row_bcast:15 row_mask:0x8 bank_mask:0xf\n\t" LMRS_DPP_ROW : "+v"(acc) : "v"(e));
+        }
+    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 16 * nrows - 1));
+}
+
 // Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() also waits for every
 // outstanding global load (s_waitcnt vmcnt(0)), which would drain the weight stream that is deliberately
 // left in flight across the activation prologue; the kernels below only ever hand LDS data across a

@@ -19,7 +19,36 @@ enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_C
                 // CLIP tower (batched GEMM only): + bias with q / sqrt(head) | + bias + residual | + bias, QuickGELU
                 EPI_VQKV = 6, EPI_BIAS_RESID = 7, EPI_BIAS_QGELU = 8,
                 // image projector (processor.rs:234-342): + bias, tanh-GELU | + bias
-                EPI_BIAS_GELU = 9, EPI_BIAS = 10 };
+                EPI_BIAS_GELU = 9, EPI_BIAS = 10,
+                // merged qkv + attention launch: q / raw k / v leave as 8-byte {value, tag} granules (write-through), v also to its cache row
+                EPI_QKV_TAG = 11 };
+
+struct EmbedArgs {
+    const void* emb_q; const float* emb_s; int q4;
+    const uint32_t* tokens;  // tokens[pos] is the input token
+    float* x; int dim; float scale; int do_scale;   // Gemma: x *= sqrt(dim)
+    const DevState* st;
+};
+
+struct ArgmaxArgs {
+    const float* part_val; const int* part_idx; int n_part;
+    int n_groups, group_stride;   // row-sharded classifier: n_groups shards of partials, group_stride entries apart (1 shard: 1, 0)
+    const float* logits;
+    int tail_row;            // > 0: logits[tail_row ..] are never written by the classifier (vocab % 4 rows, functional.rs:183) and hold 0.0
+    uint32_t* tokens; DevState* st;
+    unsigned* seq;           // optional: the context's count of finished steps (the tags of the merged qkv + attention launch), bumped here
+    EmbedArgs emb;           // the winner's (or the next prompt token's) embedding row is written to emb.x
+    unsigned long long* dbg;
+};
+
+// EPI_CLS with the final argmax folded in (one GPU): workgroup 0 of the launch consumes the partials the GEMV workgroups publish as
+// single 8-byte tagged words and does what the stand-alone argmax_final_kernel does (token feedback, position advance, next
+// embedding row) - one launch and its boundary less per step.  See cls_consumer (lmrs_kernels.hip).
+struct ClsTail {
+    unsigned long long* part_pk;   // [grid - 1] packed partials {value | nan flag, tag, index}
+    int* err;                      // set if the consumer's bounded sweep gives up
+    ArgmaxArgs m;                  // part_val / part_idx / n_part unused here; m.seq (non-null) makes the tags
+};
 
 struct GemvArgs {
     // weights: o rows of n int8 (Q8_0) / n/2 bytes (Q4_0), row-major; scales o * (n/128) f32
@@ -37,11 +66,15 @@ struct GemvArgs {
     // EPI_QKV
     float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer;
     const DevState* st;
+    // EPI_QKV_TAG: gran[row] = {value, tag = *seq + 1}; seq = steps finished so far on this context (never reset)
+    unsigned long long* gran; const unsigned* seq;
     // EPI_CLS
     float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on (global) rows < softcap_rows
     int row_offset;          // global index of this launch's row 0 (row-sharded classifier)
+    int has_tail; ClsTail tail;   // EPI_CLS: fold the final argmax into this launch (see ClsTail)
     unsigned long long* dbg; // optional: 8 wall-clock stamps (debug timeline)
     int order_barrier;       // set by launch_gemv: workgroup barrier between the activation loads and the weight tile
+    int chain_spread;        // set by launch_gemv: the RMSNorm chain of a CU's second workgroup runs on another wave (SIMD)
 };
 
 struct AttnArgs {
@@ -57,24 +90,6 @@ struct AttnArgs {
     const DevState* st;
 };
 
-struct EmbedArgs {
-    const void* emb_q; const float* emb_s; int q4;
-    const uint32_t* tokens;  // tokens[pos] is the input token
-    float* x; int dim; float scale; int do_scale;   // Gemma: x *= sqrt(dim)
-    const DevState* st;
-};
-
-struct ArgmaxArgs {
-    const float* part_val; const int* part_idx; int n_part;
-    int n_groups, group_stride;   // row-sharded classifier: n_groups shards of partials, group_stride entries apart (1 shard: 1, 0)
-    const float* logits;
-    int tail_row;            // > 0: logits[tail_row ..] are never written by the classifier (vocab % 4 rows, functional.rs:183) and hold 0.0
-    uint32_t* tokens; DevState* st;
-    EmbedArgs emb;           // the winner's (or the next prompt token's) embedding row is written to emb.x
-    unsigned* flags; int n_flag_words;   // in-launch arrival counters of the fused kernels: re-zeroed here, at the end of the step
-    unsigned long long* dbg;
-};
-
 // launches (all asynchronous on `s`)
 hipError_t launch_gemv(const GemvArgs& a, int pro, int epi, hipStream_t s, int grid_hint = 0);
 void set_gemv_launch_events(hipEvent_t start, hipEvent_t stop);   // measurement: attach events to the next GEMV dispatches (null: off)
@@ -88,6 +103,14 @@ bool gemv_is_static(const GemvArgs& a, int pro, int epi); // a compile-time-shap
 hipError_t launch_gemv_f32(const GemvArgs& a, int pro, int epi, hipStream_t s);
 int gemv_f32_grid(const GemvArgs& a, int epi);
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// qkv GEMV + attention of one layer as ONE launch (short contexts): n_heads attention workgroups, dispatched first, prefetch the K / V
+// rows of the earlier positions and poll the {value, tag} granules the GEMV workgroups of the same launch write (g.gran, g.seq).
+// max_T: longest context (pos + 1) the launch will ever see (sizes the LDS score vector).  hipErrorNotSupported: no merged class
+// for this shape - the caller launches the two kernels separately.
+struct QkvAttnArgs { GemvArgs g; AttnArgs t; int* err; };
+bool qkv_attn_supported(const GemvArgs& g, int pro, const AttnArgs& t);
+int qkv_attn_wave_T(int head_size);       // longest context (pos + 1) of the one-wave-per-head form; 0: none for this head size
+hipError_t launch_qkv_attn(const GemvArgs& g, int pro, const AttnArgs& t, int* err, int max_T, bool wave, hipStream_t s);
 // long contexts: scores by (head, 256-key chunk), softmax + V by (head, quarter of the dims); S: attention_split_scratch_floats(..)
 size_t attention_split_scratch_floats(int n_heads, int seq_len);
 hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks, hipStream_t s);
@@ -148,19 +171,5 @@ hipError_t launch_vis_patch_embed(const VisPatchArgs& a, int num_crops, hipStrea
 hipError_t launch_vis_layernorm(const float* x, const float* w, const float* b, float eps, int dim, int n_tok, float* out_f32, int8_t* xq, float* xs, hipStream_t s);
 hipError_t launch_vis_attention(const float* qkv, float* out, float* scratch, int num_crops, int n_heads, int T, int dim, hipStream_t s);
 size_t vis_attention_scratch_floats(int num_crops, int n_heads, int T);
-
-// ---- fused attention block (lmrs_fused.inc): qkv -> attention -> wo of one layer in one launch
-struct FusedAttnArgs {
-    const int8_t *wqkv, *wo; const float *sqkv, *so, *rms_att; float eps;
-    float *x, *q, *k_raw, *att_out; float *k_cache, *v_cache; const float* rope; int seq_len, layer;
-    unsigned* flags;         // this layer's two arrival-counter sets (zeroed at the end of every step)
-    int* err;                // set to stage+1 if a bounded in-launch wait ever times out
-    const DevState* st; unsigned long long* dbg;
-};
-constexpr int kFusedFlagWordsPerLayer = 2 * 8 * 16;
-int fused_attn_class(int dim, int n_heads, int n_kv_heads, int head_size, int q4, int llama_like);
-int fused_attn_grid(int cls);
-hipError_t fused_attn_prepare(int cls, int head_size, int seq_len, int* max_blocks_per_cu);
-hipError_t launch_fused_attn(int cls, const FusedAttnArgs& a, int head_size, hipStream_t s);
 
 }  // namespace lmrs

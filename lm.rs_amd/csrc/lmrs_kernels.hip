@@ -196,6 +196,134 @@ __device__ __forceinline__ void load_vec(float4 (&v)[NP], const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// Embedding row element (transformer.rs:324-332; quantization.rs:25-42) - dequantised on the fly, which is bit-identical to reading
+// the reference's load-time f32 copy of the table.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dequant_elem(const void* q, const float* s, int q4, size_t idx) {     // q4: 0 Q8_0, 1 Q4_0, 2 f32 table (q_type None)
+    if (q4 == 2) return reinterpret_cast<const float*>(q)[idx];
+    if (!q4) return (float)reinterpret_cast<const int8_t*>(q)[idx] * s[idx / kGS];
+    const int8_t v = reinterpret_cast<const int8_t*>(q)[idx >> 1];
+    const int nib = (idx & 1) ? ((v >> 4) & 0x0F) - 8 : (v & 0x0F) - 8;
+    return (float)nib * s[idx / kGS];
+}
+
+// sample_argmax (sampler.rs:29-41) over per-thread candidates (larger value wins, ties -> lower index = first index of the maximum),
+// then token feedback, position advance and the embedding row of the next input token.  Whole workgroup (kBlock threads); shared by
+// the stand-alone argmax_final_kernel and the classifier's last-arriving workgroup (ClsTail).
+// pre: the step state the tail needs (position, end of the prompt, the prompt token that may follow), loaded by the caller BEFORE its
+// long-running work when it can (the classifier: at kernel start), so that the tail is not a chain of dependent memory round trips.
+struct TailPre { int pos, prompt_end; uint32_t tok_next; };
+__device__ __forceinline__ TailPre tail_preload(const ArgmaxArgs& a) {
+    TailPre p; p.pos = a.st->pos; p.prompt_end = a.st->prompt_end; p.tok_next = a.tokens[p.pos + 1]; return p;
+}
+__device__ __forceinline__ void argmax_tail(const ArgmaxArgs& a, float best, int best_i, int nan0, const TailPre& pre) {
+    __shared__ float sv[kBlock / 64];
+    __shared__ int si[kBlock / 64];
+    __shared__ uint32_t s_next;
+    if (threadIdx.x == 0 && a.tail_row > 0 && (0.0f > best || (0.0f == best && a.tail_row < best_i))) { best = 0.0f; best_i = a.tail_row; }   // the unwritten last rows: 0.0, the first of them wins their tie
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {                   // wave: larger value, ties -> lower index
+        const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(best_i, off);
+        if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = best_i; }
+    nan0 = __syncthreads_or(nan0);
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < best_i)) { best = sv[w]; best_i = si[w]; }
+        int win = best_i;
+        if (nan0 || win == 0x7fffffff) win = 0;             // NaN at index 0 is never displaced (strict >); nothing above -inf: index 0
+        const int pos = pre.pos;
+        uint32_t next = (uint32_t)win;
+        if (pos + 1 >= pre.prompt_end) a.tokens[pos + 1] = next;     // chat.rs:188-193: sampler output ignored while the prompt lasts
+        else next = pre.tok_next;
+        a.st->pos = pos + 1;
+        a.st->step_count += 1;
+        if (a.seq) *a.seq += 1u;
+        s_next = next;
+    }
+    __syncthreads();
+    // embedding row of the next input token (transformer.rs:324-332) for the next replay of the step graph
+    const uint32_t token = s_next;
+    if (a.emb.q4 == 0 && a.emb.dim > 0 && (a.emb.dim & 7) == 0 && a.emb.dim <= 8 * 4 * kBlock) {
+        // Q8_0 rows: 8 elements per thread and pass, ALL loads of the row issued before the first use (the generic loop below is one
+        // dependent memory round trip per element: 8 of them for a 2048-wide row, 4 us on the critical path of every step)
+        const int8_t* qrow = reinterpret_cast<const int8_t*>(a.emb.emb_q) + (size_t)token * a.emb.dim;
+        const float* srow = a.emb.emb_s + ((size_t)token * a.emb.dim) / kGS;       // dim % 128 == 0: the row's scales are contiguous
+        uint2 q8[4]; float sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (k * kBlock + (int)threadIdx.x) * 8;
+            const bool live = e < a.emb.dim;
+            q8[k] = *reinterpret_cast<const uint2*>(qrow + (live ? e : 0));
+            sc[k] = srow[(live ? e : 0) / kGS];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (k * kBlock + (int)threadIdx.x) * 8;
+            if (e < a.emb.dim) {
+                float o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = (int)(int8_t)(((u < 4 ? q8[k].x : q8[k].y) >> (8 * (u & 3))) & 0xff);
+                    float v = (float)b * sc[k];
+                    if (a.emb.do_scale) v = v * a.emb.scale;
+                    o[u] = v;
+                }
+                *reinterpret_cast<float4*>(a.emb.x + e) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(a.emb.x + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < a.emb.dim; i += kBlock) {
+            float v = dequant_elem(a.emb.emb_q, a.emb.emb_s, a.emb.q4, (size_t)token * a.emb.dim + i);
+            if (a.emb.do_scale) v = v * a.emb.scale;
+            a.emb.x[i] = v;
+        }
+    }
+}
+
+// The classifier launch with the argmax folded in (ClsTail).  Every workgroup publishes its partial as ONE 8-byte write-through word
+// {value | nan-at-0 flag, 11-bit tag, 20-bit index} - the data is the flag, as in the merged qkv + attention launch - and workgroup
+// 0, once its own rows are done, sweeps the words until every tag is this step's, reduces them and finishes the step (token
+// feedback, position advance, next embedding row).  Measured alternatives: an arrival ticket (512 arrivals on one counter serialise
+// at ~12 ns each exactly when the bandwidth-bound launch ends and everybody arrives together: as slow as the separate argmax launch
+// it replaced); a dedicated consumer workgroup polling from the start (its sweeps return behind the weight tiles of the GEMV workgroup
+// it shares a CU with - a CU answers its loads in request order: the last partial was seen 4 us late).  Nobody waits for workgroup 0;
+// its sweeps are bounded (err).
+__device__ __forceinline__ unsigned cls_tag(const GemvArgs& a) { return (*a.tail.m.seq + 1u) & 0x7ffu; }
+__device__ __forceinline__ void cls_publish(const GemvArgs& a, int bid, unsigned tag, float best, int best_i) {
+    // index field: 0xfffff = "nothing above -inf in my rows" (best_i = 0x7fffffff); the host admits vocabularies below 2^20 - 1 only
+    const unsigned hi = best_i < 0 ? (0x80000000u | (tag << 20)) : ((tag << 20) | (best_i == 0x7fffffff ? 0xfffffu : (unsigned)best_i));
+    __hip_atomic_store(a.tail.part_pk + bid, ((unsigned long long)hi << 32) | __float_as_uint(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cls_consumer(const GemvArgs& a, int nprod, const TailPre& pre, unsigned tag) {
+    if (a.dbg && threadIdx.x == 0) a.dbg[4] = wall_clock64();
+    float bv; int bi, nan0;
+    for (unsigned spins = 0;; ++spins) {
+        bv = __uint_as_float(0xff800000u); bi = 0x7fffffff; nan0 = 0;
+        int ok = 1;
+        for (int i = threadIdx.x; i < nprod; i += kBlock) {
+            const unsigned long long pk = __hip_atomic_load(a.tail.part_pk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned hi = (unsigned)(pk >> 32);
+            if (((hi >> 20) & 0x7ffu) != tag) { ok = 0; continue; }
+            if (hi & 0x80000000u) { nan0 = 1; continue; }
+            const float v = __uint_as_float((unsigned)pk); const int idx = (hi & 0xfffffu) == 0xfffffu ? 0x7fffffff : (int)(hi & 0xfffffu);
+            if (v > bv || (v == bv && idx < bi)) { bv = v; bi = idx; }
+        }
+        if (__syncthreads_and(ok)) break;
+        if (spins > (1u << 18)) {                                // bounded: report and finish with garbage instead of hanging
+            if (threadIdx.x == 0) __hip_atomic_store(a.tail.err, 1000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (a.dbg && threadIdx.x == 0) a.dbg[5] = wall_clock64();
+    argmax_tail(a.tail.m, bv, bi, nan0, pre);
+    if (a.dbg && threadIdx.x == 0) a.dbg[7] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused dequant-GEMV
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ i32x4 ld_nt(const i32x4* p) { return __builtin_nontemporal_load(p); }
@@ -247,8 +375,8 @@ __device__ __forceinline__ float preq_scale(const GemvArgs& a, int g) {
 // never displaced.  The workgroup that owns global row 0 (block 0 of the launch whose row_offset is 0) reports that case by
 // storing index -1 in its partial; argmax_final_kernel - on every shard, the partials are gathered - then answers 0.
 // (Called by thread 0 after the workgroup's __syncthreads(): the logit was stored by this workgroup and has reached L2.)
-__device__ __forceinline__ int cls_flag_nan_at_zero(const GemvArgs& a, int best_i) {
-    if (blockIdx.x == 0 && a.row_offset == 0) {
+__device__ __forceinline__ int cls_flag_nan_at_zero(const GemvArgs& a, int best_i, int bid) {
+    if (bid == 0 && a.row_offset == 0) {
         const float l0 = __hip_atomic_load(a.out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!(l0 == l0)) return -1;
     }
@@ -280,6 +408,11 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     constexpr int NC = L / CL;
     static_assert(L >= CL && (L & (L - 1)) == 0 && L <= 64, "bad L");
     LMRS_STAMP(0);
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    unsigned ctag = 0; TailPre tpre{};
+    if constexpr (EPI == EPI_CLS) {
+        if (a.has_tail) { ctag = cls_tag(a); if (bid == 0) tpre = tail_preload(a.tail.m); }     // (workgroup 0 will finish the step: ClsTail)
+    }
     const int n = a.n, G = n / kGS;
     int8_t* xq = reinterpret_cast<int8_t*>(smem);                       // n bytes
     float* xs = reinterpret_cast<float*>(smem + ((n + 15) & ~15));      // G floats
@@ -317,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 sc[u] = srow[s0 + u];
             }
     };
-    if ((int)blockIdx.x < n_pass) issue(blockIdx.x, 0);
+    if (bid < n_pass) issue(bid, 0);
 
     // ---------------- prologue: build the quantised activation vector in LDS
     if constexpr (PRO == PRO_PREQ) {
@@ -345,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     bool preloaded = true;
     const int wlane = NC == 1 ? 0 : L - CL;       // lane (within the row) that owns the finished sum
 
-    for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    for (int pass = bid; pass < n_pass; pass += nblk) {
         const int row = pass * RB + wave * RW + lane / L;
         const bool valid = row < o;
         float acc = 0.0f;
@@ -391,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 }
             }
         }
-        if (pass == (int)blockIdx.x) LMRS_STAMP(2);
+        if (pass == bid) LMRS_STAMP(2);
         // ---------------- epilogue (the finished sum is replicated over the lanes of the row's last cluster)
         if constexpr (EPI == EPI_STORE) {
             if (valid && r == wlane) a.out[row] = acc;
@@ -451,9 +584,11 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         if (threadIdx.x == 0) {
             for (int w2 = 1; w2 < kBlock / 64; ++w2)
                 if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
-            best_i = cls_flag_nan_at_zero(a, best_i);
-            a.part_val[blockIdx.x] = best; a.part_idx[blockIdx.x] = best_i;
+            best_i = cls_flag_nan_at_zero(a, best_i, bid);
+            if (!a.has_tail) { a.part_val[bid] = best; a.part_idx[bid] = best_i; }
+            else cls_publish(a, bid, ctag, best, best_i);
         }
+        if (a.has_tail && bid == 0) { __syncthreads(); cls_consumer(a, nblk, tpre, ctag); }     // workgroup-uniform
     }
 }
 
@@ -464,16 +599,17 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
 // HBM latency with counted vmcnt waits; further passes are double-buffered (tile p+1 in flight while p is
 // consumed).
 // ------------------------------------------------------------------------------------------------
-#define LMRS_STAMP0(k) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0) a.dbg[k] = wall_clock64(); } while (0)
+#define LMRS_STAMP0(k) do { if (a.dbg && threadIdx.x == 0 && bid == 0) a.dbg[k] = wall_clock64(); } while (0)
 // Q4: packed-nibble weights and the reference's Q4_0 activation quantiser (lmrs_stage.h).
 // PRO_ADD_RMS_QUANT (Gemma-2, transformer.rs:563-572 / 643-650 + the next norm): x' = x + rmsnorm(delta, add_w) is formed by
 // every workgroup from the previous GEMV's output vector `delta` - that folds the reference's separate
 // "x += rmsnorm(branch output)" step into the prologue of the kernel that consumes x' (one launch less per branch, a
 // second serial norm chain more) - and workgroup 0 stores x' to `xout`, a DIFFERENT buffer from `xin` (the other
 // workgroups are still reading it); the caller ping-pongs the two residual buffers.
+// (device body: `bid` of `nblk` workgroups - the stand-alone launch passes bid / nblk, the merged qkv + attention
+// launch the index among its GEMV workgroups)
 template <int N, int L, int PRO, int EPI, int NTH, bool Q4 = false>
-__global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, const int bid, const int nblk) {
     using R = RowGeom<N, L, NTH, Q4>;
     using V = VecGeom<N, NTH>;
     LMRS_STAMP0(0);
@@ -485,8 +621,13 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     const int8_t* wq = reinterpret_cast<const int8_t*>(a.wq);
     constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT;
 
-    int pos_pre = 0;
-    if constexpr (EPI == EPI_QKV) pos_pre = a.st->pos;      // the kernel's first load: nothing it has to wait behind
+    unsigned ctag = 0; TailPre tpre{};
+    if constexpr (EPI == EPI_CLS) {
+        if (a.has_tail) { ctag = cls_tag(a); if (bid == 0) tpre = tail_preload(a.tail.m); }     // (workgroup 0 will finish the step: ClsTail)
+    }
+    int pos_pre = 0; unsigned tag_pre = 0;
+    if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_TAG) pos_pre = a.st->pos;      // the kernel's first load: nothing it has to wait behind
+    if constexpr (EPI == EPI_QKV_TAG) tag_pre = *a.seq + 1u;
     float4 v[V::NP], nw[V::NP], dl[V::NP], aw[V::NP];
     if constexpr (PRO != PRO_PREQ) {
         if constexpr (PRO == PRO_ADD_RMS_QUANT) { vec_load<N, false, NTH>(dl, a.delta); vec_load<N, false, NTH>(aw, a.add_w); }
@@ -502,7 +643,7 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     if (PRO != PRO_PREQ && a.order_barrier) __builtin_amdgcn_s_barrier();
     // (waiting for the activation before issuing the tile, or issuing only part of it first, was measured: no gain)
     WTile<R::U> ta, tb;
-    int pass = blockIdx.x;                      // grid <= n_pass
+    int pass = bid;                      // grid <= n_pass
     tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(pass));
     // (requesting the second pass's tile here as well - it would stream under the prologue - was measured slower on every model, Gemma's
     // 5 us folded prologue included: the more bytes are queued ahead of a workgroup's activation loads, the later they land)
@@ -522,20 +663,20 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
             *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(preq_bytes(a, e));
         for (int g = threadIdx.x; g < V::G; g += NTH) xs[g] = preq_scale(a, g);
     } else {
-        unsigned long long* dbg = blockIdx.x == 0 ? a.dbg : nullptr;
+        unsigned long long* dbg = bid == 0 ? a.dbg : nullptr;
         if constexpr (PRO == PRO_ADD_RMS_QUANT) {
             vec_rmsnorm<N, NTH>(dl, aw, a.eps, a.add_unit, scratch);                 // rmsnorm(branch output)
 #pragma unroll
             for (int i = 0; i < V::NP; ++i) {
                 v[i].x = v[i].x + dl[i].x; v[i].y = v[i].y + dl[i].y; v[i].z = v[i].z + dl[i].z; v[i].w = v[i].w + dl[i].w;   // x[i] += emb[i]
                 const int e = i * V::PER + (int)threadIdx.x * 4;
-                if (blockIdx.x == 0 && (V::FULL || i < V::NP - 1 || e < N)) *reinterpret_cast<float4*>(a.xout + e) = v[i];
+                if (bid == 0 && (V::FULL || i < V::NP - 1 || e < N)) *reinterpret_cast<float4*>(a.xout + e) = v[i];
             }
         }
-        if constexpr (HAS_RMS) vec_rmsnorm<N, NTH>(v, nw, a.eps, a.add_unit, scratch, dbg);
+        if constexpr (HAS_RMS) vec_rmsnorm<N, NTH>(v, nw, a.eps, a.add_unit, scratch, dbg, NoHook(), a.chain_spread ? (((int)blockIdx.x >> 8) * 2) & (NTH / 64 - 1) : 0);
         if constexpr (Q4) vec_quantize_q4<N, NTH>(v, xq, xs, dbg);
         else vec_quantize_q8<N, NTH>(v, xq, xs, dbg);
-        if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[7] = wall_clock64();
+        if (a.dbg && bid == 0 && threadIdx.x == 0) a.dbg[7] = wall_clock64();
     }
     lds_barrier();
     LMRS_STAMP0(1);
@@ -549,12 +690,19 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
         if constexpr (EPI == EPI_STORE) {
             if (valid && writer) a.out[row] = acc;
         } else if constexpr (EPI == EPI_RESID) {
-            if (valid && writer) a.out[row] = (ps == (int)blockIdx.x ? resid0 : a.out[row]) + acc;
+            if (valid && writer) a.out[row] = (ps == bid ? resid0 : a.out[row]) + acc;
         } else if constexpr (EPI == EPI_QKV) {
             if (valid && writer) {
                 if (row < a.att_dim) a.out[row] = acc;
                 else if (row < a.att_dim + a.kv_dim) a.k_raw[row - a.att_dim] = acc;
                 else a.v_cache[((size_t)a.layer * a.seq_len + pos_pre) * a.kv_dim + (row - a.att_dim - a.kv_dim)] = acc;
+            }
+        } else if constexpr (EPI == EPI_QKV_TAG) {
+            // the attention workgroups of the SAME launch are polling for these: one aligned 8-byte write-through store per value,
+            // the tag in the upper half (the data is the flag: no fence, no counter)
+            if (valid && writer) {
+                __hip_atomic_store(a.gran + row, ((unsigned long long)tag_pre << 32) | __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (row >= a.att_dim + a.kv_dim) a.v_cache[((size_t)a.layer * a.seq_len + pos_pre) * a.kv_dim + (row - a.att_dim - a.kv_dim)] = acc;   // for the later steps
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
             const float up = __shfl_down(acc, L);                       // rows interleaved: 2i gate, 2i+1 up
@@ -582,12 +730,12 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
         // whole instruction stream however few lanes need it, and only one lane in 2L holds a (gate, up) pair.  So the passes are
         // taken two at a time: the second pass's pair moves one lane up (DPP row_shr:1, same 16-lane row) and ONE evaluation serves both.
         for (;;) {
-            const int p1 = pass + gridDim.x;
+            const int p1 = pass + nblk;
             const bool have1 = p1 < n_pass;
             if (have1) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));
             const float acc_a = tile_consume<N, L, Q4>(ta, xq, xs);
-            if (pass == (int)blockIdx.x) LMRS_STAMP0(2);
-            const int p2 = p1 + gridDim.x;
+            if (pass == bid) LMRS_STAMP0(2);
+            const int p2 = p1 + nblk;
             const bool have2 = have1 && p2 < n_pass;
             float acc_b = 0.0f;
             if (have1) {                                                   // wave-uniform
@@ -611,12 +759,12 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
     } else
     // double-buffered passes
     for (;;) {
-        const int p1 = pass + gridDim.x;
+        const int p1 = pass + nblk;
         if (p1 < n_pass) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));
         finish(tile_consume<N, L, Q4>(ta, xq, xs), pass);
-        if (pass == (int)blockIdx.x) LMRS_STAMP0(2);
+        if (pass == bid) LMRS_STAMP0(2);
         if (p1 >= n_pass) break;
-        const int p2 = p1 + gridDim.x;
+        const int p2 = p1 + nblk;
         if (p2 < n_pass) tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(p2));
         finish(tile_consume<N, L, Q4>(tb, xq, xs), p1);
         if (p2 >= n_pass) break;
@@ -636,10 +784,20 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
         if (threadIdx.x == 0) {
             for (int w2 = 1; w2 < NTH / 64; ++w2)
                 if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
-            best_i = cls_flag_nan_at_zero(a, best_i);
-            a.part_val[blockIdx.x] = best; a.part_idx[blockIdx.x] = best_i;
+            best_i = cls_flag_nan_at_zero(a, best_i, bid);
+            if (!a.has_tail) { a.part_val[bid] = best; a.part_idx[bid] = best_i; }
+            else cls_publish(a, bid, ctag, best, best_i);
+        }
+        if constexpr (NTH == kBlock) {
+            if (a.has_tail && bid == 0) { __syncthreads(); cls_consumer(a, nblk, tpre, ctag); }     // workgroup-uniform
         }
     }
+}
+
+template <int N, int L, int PRO, int EPI, int NTH, bool Q4 = false>
+__global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemv_static_body<N, L, PRO, EPI, NTH, Q4>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Static classes (N, L, PRO, EPI, threads, Q4): the instantiated shapes of the supported model families.
@@ -736,7 +894,7 @@ static void allow_big_lds(const void* fn) {
 static size_t gemv_smem(const GemvArgs& a, int pro) {
     const int n = a.n, G = n / kGS;
     size_t s = ((n + 15) & ~15) + (size_t)((G + 3) & ~3) * 4;
-    if (pro == PRO_RMS_QUANT || pro == PRO_ADD_RMS_QUANT) s += (size_t)(8 * (n / 8 + 4) + 4) * 4;
+    if (pro == PRO_RMS_QUANT || pro == PRO_ADD_RMS_QUANT) s += (size_t)rms_scratch_floats(n) * 4;
     return s < 64 ? 64 : s;
 }
 
@@ -825,10 +983,12 @@ int gemv_grid(const GemvArgs& a, int pro, int epi) {
 
 hipError_t launch_gemv(const GemvArgs& a0, int pro, int epi, hipStream_t s, int grid_hint) {
     static const int order_barrier = env_flag("LMRS_ORDER_BARRIER", 1);
+    static const int chain_spread = env_flag("LMRS_CHAIN_SPREAD", 1);
     GemvArgs a = a0;
-    a.order_barrier = order_barrier;
+    a.order_barrier = order_barrier; a.chain_spread = chain_spread;
     if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
     const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
+    if (epi == EPI_CLS && a.has_tail && (!a.tail.m.seq || !a.tail.err || !a.tail.part_pk || a.o + a.row_offset >= (1 << 20) - 1)) return hipErrorInvalidValue;
     const size_t smem = gemv_smem(a, pro);
     const StaticClass sc = static_class(a, pro, epi);
     if (sc.L) {
@@ -1007,9 +1167,15 @@ __device__ __forceinline__ float att_score_chain(f32x4v (&kk)[NG], __amdgpu_buff
 
 // GEMMA: score soft-cap + window mask (a compile-time switch: the f64 tanh is ~230 instructions and a dozen registers)
 // ROT (batched prefill): q is already rotated and the key of `pos` already in the cache (rope_rows_kernel).
-template <int HS, int NF, bool COH, bool PRE = false, bool GEMMA = false, bool ROT = false>
-__device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, uint64_t etab, const AttPre& pre = AttPre()) {
+// TAG (merged qkv + attention launch): q, the raw key and the value row of this position are produced by the GEMV workgroups of
+// the SAME launch as 8-byte {value, tag} granules (EPI_QKV_TAG); the lanes that need them poll the granules themselves, after
+// all K / V loads of the earlier positions have been issued.
+struct AttTag { const unsigned long long* gran; unsigned tag; int att_dim, kv_dim; int* err; };
+constexpr unsigned kTagSpinMax = 1u << 20;
+template <int HS, int NF, bool COH, bool PRE = false, bool GEMMA = false, bool ROT = false, bool TAG = false>
+__device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, uint64_t etab, const AttPre& pre = AttPre(), const AttTag& tg = AttTag()) {
     static_assert(!PRE || HS / 2 <= kBlock, "one RoPE pair per lane");
+    static_assert(!TAG || (HS <= kBlock && !COH && !PRE && !ROT), "granule polling: one value of each vector per lane");
     constexpr int half = HS / 2, RS = HS + 4;
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul;
     const int kv_dim = a.n_kv_heads * HS;
@@ -1038,11 +1204,53 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     att_gload<HS, NF>(vreg, vbase, 0, T, CH, kv_dim);  // row `pos` of V was stored by the QKV kernel (COH: patched from vn)
 
     if constexpr (ROT) { for (int j = tid; j < HS; j += kBlock) q[j] = a.q[h * HS + j]; }
+    float2 cs_tag = make_float2(0.f, 0.f);
+    if constexpr (TAG) {
+        cs_tag = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + (tid < half ? tid : 0)) * 2);   // ahead of the polls
+        if (tid < HS) {
+            const unsigned long long* gq = tg.gran + h * HS + tid;
+            const unsigned long long* gk = tg.gran + tg.att_dim + kvh * HS + tid;
+            const unsigned long long* gv = tg.gran + tg.att_dim + tg.kv_dim + kvh * HS + tid;
+            unsigned long long x0, x1, x2;
+            for (unsigned spins = 0;; ++spins) {
+                x0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x1 = __hip_atomic_load(gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x2 = __hip_atomic_load(gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = (unsigned)(x0 >> 32) == tg.tag && (unsigned)(x1 >> 32) == tg.tag && (unsigned)(x2 >> 32) == tg.tag;
+                if (__all(ok)) break;
+                if (spins > kTagSpinMax || (spins & 1023) == 1023) {     // bounded: report and finish with garbage instead of hanging
+                    const int e = __hip_atomic_load(tg.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e != 0 || spins > kTagSpinMax) {
+                        if (e == 0) __hip_atomic_store(tg.err, a.layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            q[tid] = __uint_as_float((unsigned)x0); kn[tid] = __uint_as_float((unsigned)x1); vn[tid] = __uint_as_float((unsigned)x2);
+        }
+        lds_barrier();
+        ATT_STAMP(1);
+    }
     // RoPE (transformer.rs:480-491) with the host-built (fcr, fci) table
     for (int j = tid; j < (ROT ? 0 : half); j += kBlock) {
         float2 cs;
-        if constexpr (PRE) cs = pre.cs; else cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
+        if constexpr (PRE) cs = pre.cs; else if constexpr (TAG) cs = cs_tag; else cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + j) * 2);
         const float fcr = cs.x, fci = cs.y;
+        if constexpr (TAG) {                                   // raw values in place in LDS; this thread owns both halves of pair j
+            {
+                const float v0 = q[j], v1 = q[j + half];
+                const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+                q[j] = a0 - a1; q[j + half] = b0 + b1;
+            }
+            const float v0 = kn[j], v1 = kn[j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            const float r0 = a0 - a1, r1 = b0 + b1;
+            kn[j] = r0; kn[j + half] = r1;
+            kT[(((size_t)(j >> 2) * S + pos) << 2) + (j & 3)] = r0;
+            kT[(((size_t)((j + half) >> 2) * S + pos) << 2) + ((j + half) & 3)] = r1;
+            continue;
+        }
         {
             const float v0 = PRE ? pre.q0 : ld_f32<COH>(a.q + h * HS + j), v1 = PRE ? pre.q1 : ld_f32<COH>(a.q + h * HS + j + half);
             const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
@@ -1127,7 +1335,7 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
     float o = 0.0f;
     for (int c = 0; c < nchunks; ++c) {
         const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore<HS, NF, true>(vreg, tile, att + t0, t0, T, CH, COH ? pos : -1, vn);
+        att_tstore<HS, NF, true>(vreg, tile, att + t0, t0, T, CH, (COH || TAG) ? pos : -1, vn);
         lds_barrier();
         if (c + 1 < nchunks) att_gload<HS, NF>(vreg, vbase, t0 + CH, T, CH, kv_dim);
         if (c == 0) ATT_STAMP(6);
@@ -1192,6 +1400,367 @@ hipError_t launch_attention(const AttnArgs& a0, hipStream_t s) {
         case 256: return launch_attention_hs<256>(a, smem, s);  // Gemma-2
         default: return hipErrorInvalidValue;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// qkv projection + attention of one layer in ONE launch (short contexts).
+// As two launches this edge costs a dependent kernel boundary (1.6 us) plus the attention kernel's own ramp (position -> K / V
+// loads -> q: 1.2 us before its RoPE step) although only the 4 query heads + 1 key + 1 value head of a kv group meet in an
+// attention workgroup - a few-to-one edge, not an all-to-all one.  Here the n_heads attention workgroups are the FIRST workgroups
+// of the grid: they issue every K / V load of the earlier positions, then poll the 3 x HS {value, tag} granules they need
+// (Guideline-16 "R2": one aligned 8-byte write-through store per value, the data is the flag - no counter, no fence, correct under
+// any workgroup placement); the GEMV workgroups behind them are the unchanged static kernel body with the EPI_QKV_TAG epilogue.
+// The attention workgroups never block a GEMV workgroup (nobody waits for them inside the launch), so the launch cannot deadlock
+// whatever the residency; every poll loop is bounded (err).  Arithmetic: the bodies of the separate kernels - bit-identical.
+// ------------------------------------------------------------------------------------------------
+// ---- one WAVE per query head (merged launch, the shortest contexts: T = pos + 1 <= TW) -------------------------------------------
+// A whole workgroup per head pays a workgroup barrier (and an LDS round trip) between any two phases for a context of a few dozen
+// keys, where each phase is a handful of instructions.  Here a single wave runs the head start to finish with no barrier at all:
+//   before q arrives (free time, the qkv workgroups are still streaming): the keys of the earlier positions go into an LDS tile
+//   kt[dim group][t][4] (the blocked cache layout: lane t later reads its own key 16 bytes at a time, conflict-free), the value rows
+//   into REGISTERS, v[t] = v_t[lane] (one coalesced 256-byte row per load): the chain lane of output dim d already holds its column;
+//   then: poll the granules (lane d: q[d], k[d], v[d]), RoPE through LDS, scores one lane per key (pass p: keys 64p .. 64p+63),
+//   max by DPP, exp, the sum chain run redundantly by every lane (no broadcast), divide, and the V chain o += a_t * v[t] with the
+//   weights read back four at a time as LDS broadcasts.  Slots past the sequence carry weight +0.0 and value 0.0: exact no-ops.
+// Same operations in the same order per value as attention_body: bit-identical.
+template <int HS> struct WaveGeom {
+    static constexpr int HS4 = HS / 4, ND = (HS + 63) / 64, NH2 = (HS / 2 + 63) / 64;
+    static constexpr int TW = HS <= 64 ? 128 : 64;                  // longest context: ND * TW value registers, HS * TW * 4 bytes of keys in LDS
+    static constexpr int NPASS = TW / 64;
+    static constexpr size_t SMEM = (size_t)(2 * HS + TW + 16) * 4 + (size_t)HS4 * TW * 16;
+};
+constexpr int qa_wave_T(int hs) { return hs == 64 ? 128 : ((hs == 96 || hs == 128) ? 64 : 0); }   // 0: no wave class (Gemma's 256-wide heads)
+
+template <int HS, bool GEMMA>
+__device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
+    using W = WaveGeom<HS>;
+    constexpr int HS4 = W::HS4, ND = W::ND, NH2 = W::NH2, TW = W::TW, NPASS = W::NPASS, half = HS / 2;
+    const int lane = threadIdx.x;                                   // the caller retired threads 64..
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul, kv_dim = a.n_kv_heads * HS;
+    const int T = pos + 1, S = a.seq_len;
+    float* qs = reinterpret_cast<float*>(smem);                     // HS: rotated query
+    float* kn = qs + HS;                                            // HS: raw, then rotated key of this position
+    float* att = kn + HS;                                           // TW + 16: exponentials, then weights
+    float4* kt = reinterpret_cast<float4*>(att + TW + 16);          // [HS4][TW] x 16 bytes
+    float* kT = att_k_head(a, kvh, HS);
+    const float* vbase = a.v_cache + (size_t)a.layer * S * kv_dim + kvh * HS;
+    if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[0] = wall_clock64();
+
+    // ---- RoPE terms of this position, keys and values of the earlier ones: all before the first poll
+    float2 cs[NH2];
+#pragma unroll
+    for (int i = 0; i < NH2; ++i) { const int j = lane + 64 * i; cs[i] = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + (j < half ? j : 0)) * 2); }
+    // Keys: LDS-DMA (global_load_lds_dwordx4: lane t's 16 bytes land at tile + 16 t, no registers, nothing to wait for until the
+    // scores).  Rows past the sequence are read as they lie in the cache (the host guarantees TW <= seq_len): those lanes' scores are
+    // replaced below, and slot `pos` is overwritten with the rotated new key once the DMA has landed.
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        if (64 * p < pos) {                                         // wave-uniform
+#pragma unroll
+            for (int g = 0; g < HS4; ++g)
+                __builtin_amdgcn_global_load_lds((const LMRS_GLOBAL void*)(kT + ((size_t)g * S + 64 * p + lane) * 4),
+                                                 (__attribute__((address_space(3))) void*)(kt + g * TW + 64 * p), 16, 0, 0);
+        }
+    }
+    // Values: v[t] = v_t[this lane's dims], one 256-byte row per load (buffer loads: the row offset is a scalar), blocks of 16 rows
+    // NESTED so that the whole prefetch has ONE join (a join after every block made hipcc drain the loads there: 5.8 us for 100 rows).
+    float v[ND][TW];
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vbase), 0, 0x7fffffff, 0x00020000);
+    const int vrow = kv_dim * 4;
+    auto vblock = [&](auto self, auto t0c) __attribute__((always_inline)) -> void {
+        constexpr int t0 = decltype(t0c)::value;
+        if constexpr (t0 < TW) {
+            if (t0 < pos) {                                         // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) {
+                        const int d = lane + 64 * i;
+                        v[i][t0 + u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vrs, (d < HS ? d : 0) * 4, (t0 + u) * vrow, 0));
+                    }
+                self(self, std::integral_constant<int, t0 + 16>());
+            }
+        }
+    };
+    vblock(vblock, std::integral_constant<int, 0>());
+    // slots past the sequence: 0.0 (what lies in the cache there must not meet its +0.0 weight as Inf / NaN); pinned HERE, ahead of the
+    // polls (left alone the selects sink into the V chain, one scalar compare + select per add on the critical path)
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { v[i][t] = t < pos ? v[i][t] : 0.0f; asm volatile("" : "+v"(v[i][t])); }
+    if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[1] = wall_clock64();
+
+    // ---- q, raw k, v of this position: poll the granules (two sweeps in flight: a sweep's latency, not twice it, after the store)
+    unsigned long long xg[3 * ND];
+    {
+        const unsigned long long* gp[3 * ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d = lane + 64 * i, dc = d < HS ? d : 0;
+            gp[3 * i] = tg.gran + h * HS + dc; gp[3 * i + 1] = tg.gran + tg.att_dim + kvh * HS + dc; gp[3 * i + 2] = tg.gran + tg.att_dim + tg.kv_dim + kvh * HS + dc;
+        }
+        auto sweep = [&](unsigned long long (&x)[3 * ND]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 3 * ND; ++k) x[k] = __hip_atomic_load(gp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto fresh = [&](const unsigned long long (&x)[3 * ND]) __attribute__((always_inline)) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 3 * ND; ++k) ok = ok && (unsigned)(x[k] >> 32) == tg.tag;
+            return __all(ok) != 0;
+        };
+        unsigned long long xa[3 * ND], xb[3 * ND];
+        sweep(xa);
+        for (unsigned spins = 0;; ++spins) {
+            sweep(xb);
+            if (fresh(xa)) {
+#pragma unroll
+                for (int k = 0; k < 3 * ND; ++k) xg[k] = xa[k];
+                break;
+            }
+            sweep(xa);
+            if (fresh(xb)) {
+#pragma unroll
+                for (int k = 0; k < 3 * ND; ++k) xg[k] = xb[k];
+                break;
+            }
+            if (spins > kTagSpinMax || (spins & 1023) == 1023) {     // bounded: report and finish with garbage instead of hanging
+                const int e = __hip_atomic_load(tg.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e != 0 || spins > kTagSpinMax) {
+                    if (e == 0) __hip_atomic_store(tg.err, a.layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 3 * ND; ++k) xg[k] = xb[k];
+                    break;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (loads return in order: the key tile's DMA landed before the granules did)
+    if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[2] = wall_clock64();
+    float vnew[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int d = lane + 64 * i;
+        vnew[i] = __uint_as_float((unsigned)xg[3 * i + 2]);
+        if (d < HS) { qs[d] = __uint_as_float((unsigned)xg[3 * i]); kn[d] = __uint_as_float((unsigned)xg[3 * i + 1]); }
+    }
+    // RoPE (transformer.rs:480-491): this lane owns both halves of pair j; the rotated key goes to the cache (for the later steps)
+    // and into the LDS tile at t = pos like every other key
+#pragma unroll
+    for (int i = 0; i < NH2; ++i) {
+        const int j = lane + 64 * i;
+        if (j < half) {
+            const float fcr = cs[i].x, fci = cs[i].y;
+            {
+                const float v0 = qs[j], v1 = qs[j + half];
+                const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+                qs[j] = a0 - a1; qs[j + half] = b0 + b1;
+            }
+            const float v0 = kn[j], v1 = kn[j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            const float r0 = a0 - a1, r1 = b0 + b1;
+            kT[(((size_t)(j >> 2) * S + pos) << 2) + (j & 3)] = r0;
+            kT[(((size_t)((j + half) >> 2) * S + pos) << 2) + ((j + half) & 3)] = r1;
+            reinterpret_cast<float*>(kt)[(((j >> 2) * TW + pos) << 2) + (j & 3)] = r0;
+            reinterpret_cast<float*>(kt)[((((j + half) >> 2) * TW + pos) << 2) + ((j + half) & 3)] = r1;
+        }
+    }
+    if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[3] = wall_clock64();
+
+    // ---- scores (transformer.rs:507-529): one lane per key, sequential dot over the head dims
+    int wpos = pos;
+    if constexpr (GEMMA) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
+    const float sqrt_hs = sqrtf((float)HS), ninf = __uint_as_float(0xff800000u);
+    float sc[NPASS];
+    float lmax = ninf;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        sc[p] = ninf;
+        if (64 * p < T) {                                           // wave-uniform
+            const int t = 64 * p + lane;
+            float score = 0.0f;
+            // batches of 4 dim groups (8 x 16-byte LDS reads) ping-pong one ahead of the adds; the running sum passes through an
+            // opaque asm per batch so that the next batch's reads are ISSUED before this batch's arithmetic
+            constexpr int GB = 4;
+            static_assert(HS4 % (2 * GB) == 0, "head size");
+            float4 ka[GB], qa[GB], kb[GB], qb[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { ka[u] = kt[u * TW + t]; qa[u] = reinterpret_cast<const float4*>(qs)[u]; }
+#pragma unroll
+            for (int g0 = 0; g0 < HS4; g0 += 2 * GB) {
+#pragma unroll
+                for (int u = 0; u < GB; ++u) { kb[u] = kt[(g0 + GB + u) * TW + t]; qb[u] = reinterpret_cast<const float4*>(qs)[g0 + GB + u]; }
+                asm volatile("" : "+v"(score) : : "memory");
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                    float pr;
+                    pr = qa[u].x * ka[u].x; score = score + pr;
+                    pr = qa[u].y * ka[u].y; score = score + pr;
+                    pr = qa[u].z * ka[u].z; score = score + pr;
+                    pr = qa[u].w * ka[u].w; score = score + pr;
+                }
+                if (g0 + 2 * GB < HS4) {
+#pragma unroll
+                    for (int u = 0; u < GB; ++u) { ka[u] = kt[(g0 + 2 * GB + u) * TW + t]; qa[u] = reinterpret_cast<const float4*>(qs)[g0 + 2 * GB + u]; }
+                }
+                asm volatile("" : "+v"(score) : : "memory");
+#pragma unroll
+                for (int u = 0; u < GB; ++u) {
+                    float pr;
+                    pr = qb[u].x * kb[u].x; score = score + pr;
+                    pr = qb[u].y * kb[u].y; score = score + pr;
+                    pr = qb[u].z * kb[u].z; score = score + pr;
+                    pr = qb[u].w * kb[u].w; score = score + pr;
+                }
+            }
+            score = score / sqrt_hs;
+            if constexpr (GEMMA) {                                  // transformer.rs:518-526
+                score = score / 50.0f;
+                score = (float)tanh((double)score);
+                score = score * 50.0f;
+                score = score + (((unsigned)(wpos - t) <= 4096u) ? 0.0f : -2.3819763e38f);
+            }
+            sc[p] = t < T ? score : ninf;
+            lmax = fmaxf(lmax, sc[p]);
+        }
+    }
+    if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[4] = wall_clock64();
+    // ---- softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
+    const float mx = wave64_max(lmax);
+    float ex[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        ex[p] = 0.0f;
+        if (64 * p < T) {                                           // wave-uniform: whole waves call expf together (it shuffles)
+            const int t = 64 * p + lane;
+            const float e = expf_glibc_t(t < T ? sc[p] - mx : 0.0f, etab);
+            ex[p] = t < T ? e : 0.0f;
+        }
+    }
+    float sum = 0.0f;                                               // sequential over t: in registers, lane by lane (wave_serial_sum)
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        if (64 * p < T) {                                           // wave-uniform; the lanes past T hold +0.0 (exact: the running sum is >= +0)
+            const int left = T - 64 * p;
+            sum = wave_serial_sum(sum, ex[p], left >= 64 ? 4 : (left + 15) >> 4);
+        }
+    }
+    float ap_lane = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        if (64 * p < T) {
+            const int t = 64 * p + lane;
+            const float w = ex[p] / sum;
+            att[t] = t < pos ? w : 0.0f;                             // the chain below covers the earlier positions; this one follows from registers
+            if ((pos >> 6) == p) ap_lane = w;
+        }
+    }
+    const float a_pos = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ap_lane), pos & 63));
+    if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[5] = wall_clock64();
+    // ---- weighted sum of values (transformer.rs:533-541), t ascending; this lane's dims
+    float o[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] = 0.0f;
+#pragma unroll
+    for (int t0 = 0; t0 < TW; t0 += 16) {
+        if (t0 < pos) {                                             // wave-uniform
+            float4 w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w4[u] = reinterpret_cast<const float4*>(att)[t0 / 4 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < ND; ++i) {
+                    float pr;
+                    pr = w4[u].x * v[i][t0 + 4 * u + 0]; o[i] = o[i] + pr;
+                    pr = w4[u].y * v[i][t0 + 4 * u + 1]; o[i] = o[i] + pr;
+                    pr = w4[u].z * v[i][t0 + 4 * u + 2]; o[i] = o[i] + pr;
+                    pr = w4[u].w * v[i][t0 + 4 * u + 3]; o[i] = o[i] + pr;
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int d = lane + 64 * i;
+        const float pr = a_pos * vnew[i];
+        o[i] = o[i] + pr;
+        if (d < HS) a.out[h * HS + d] = o[i];
+    }
+    if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
+}
+
+constexpr int qa_chunk(int hs) { return (8192 / hs) & ~31; }        // V rows per LDS tile: 64 -> 128, 96 -> 64, 128 -> 64, 256 -> 32
+template <int HS> struct QaGeom { static constexpr int CH = qa_chunk(HS), NF = (CH * (HS / 4) + kBlock - 1) / kBlock; };
+
+template <int N, int L, int PRO, bool Q4, int HS, bool GEMMA, bool WAVE>
+__global__ __launch_bounds__(kBlock) void qkv_attn_kernel(const QkvAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nh = a.t.n_heads;
+    if ((int)blockIdx.x < nh) {
+        if constexpr (WAVE) { if (threadIdx.x >= 64) return; }     // one wave per head: no barrier below
+        const uint64_t etab = exp2f_tab_lane();
+        const int pos = a.t.st->pos;
+        const AttTag tg{a.g.gran, *a.g.seq + 1u, a.g.att_dim, a.g.kv_dim, a.err};
+        if constexpr (WAVE) attention_wave_tag<HS, GEMMA>(a.t, (int)blockIdx.x, pos, smem, etab, tg);
+        else attention_body<HS, QaGeom<HS>::NF, false, false, GEMMA, false, true>(a.t, (int)blockIdx.x, pos, smem, etab, AttPre(), tg);
+    } else {
+        gemv_static_body<N, L, PRO, EPI_QKV_TAG, kBlock, Q4>(a.g, smem, (int)blockIdx.x - nh, (int)gridDim.x - nh);
+    }
+}
+
+// the merged classes: (N, L, PRO, Q4) of the model's qkv launch x (head size, Gemma score path)
+#define LMRS_QA_TABLE(X)                                                                                                \
+    X(2048, 32, PRO_RMS_QUANT, false, 64, false)      /* Llama-3.2-1B Q8_0 */                                            \
+    X(3072, 32, PRO_RMS_QUANT, false, 128, false)     /* Llama-3.2-3B Q8_0 */                                            \
+    X(3072, 16, PRO_RMS_QUANT, false, 96, false)      /* Phi-3.5 Q8_0 */                                                 \
+    X(2304, 16, PRO_RMS_QUANT, false, 256, true) X(2304, 16, PRO_ADD_RMS_QUANT, false, 256, true)   /* Gemma-2-2B Q8_0 */  \
+    X(2304, 8, PRO_RMS_QUANT, true, 256, true) X(2304, 8, PRO_ADD_RMS_QUANT, true, 256, true)       /* Gemma-2-2B Q4_0 */  \
+    X(2048, 16, PRO_RMS_QUANT, true, 64, false)       /* Llama-3.2-1B Q4_0 */
+
+bool qkv_attn_supported(const GemvArgs& g, int pro, const AttnArgs& t) {
+    const StaticClass sc = static_class(g, pro, EPI_QKV);
+    if (!sc.L || sc.nt != kBlock || t.n_heads <= 0) return false;
+#define X(n_, l_, p_, q_, hs_, gm_) if (g.n == n_ && sc.L == l_ && pro == p_ && (g.q4 != 0) == q_ && t.head_size == hs_ && (t.gemma != 0) == gm_) return true;
+    LMRS_QA_TABLE(X)
+#undef X
+    return false;
+}
+int qkv_attn_wave_T(int head_size) { return qa_wave_T(head_size); }
+
+template <int N, int L, int PRO, bool Q4, int HS, bool GEMMA>
+static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t gsmem, int max_T, bool wave, hipStream_t s) {
+    if constexpr (qa_wave_T(HS) > 0) {
+        if (wave) {
+            size_t smem = WaveGeom<HS>::SMEM > gsmem ? WaveGeom<HS>::SMEM : gsmem;
+            LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), dim3(grid), kBlock, smem, s, a);
+            return hipGetLastError();
+        }
+    }
+    if (wave) return hipErrorNotSupported;
+    size_t smem = attention_smem(HS, qa_chunk(HS), max_T);
+    if (gsmem > smem) smem = gsmem;
+    if (smem > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>));
+    LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>), dim3(grid), kBlock, smem, s, a);
+    return hipGetLastError();
+}
+
+// wave: one wave per head (contexts up to qkv_attn_wave_T(head_size)); else one workgroup per head (contexts up to max_T)
+hipError_t launch_qkv_attn(const GemvArgs& g0, int pro, const AttnArgs& t0, int* err, int max_T, bool wave, hipStream_t s) {
+    static const int order_barrier = env_flag("LMRS_ORDER_BARRIER", 1);
+    if (!qkv_attn_supported(g0, pro, t0) || !g0.gran || !g0.seq || !err) return hipErrorNotSupported;
+    QkvAttnArgs a{g0, t0, err};
+    a.g.order_barrier = order_barrier; a.g.chain_spread = env_flag("LMRS_CHAIN_SPREAD", 1);
+    a.t.chunk = qa_chunk(t0.head_size);
+    const StaticClass sc = static_class(a.g, pro, EPI_QKV);
+    const int grid = t0.n_heads + gemv_grid(a.g, pro, EPI_QKV);
+    const size_t gsmem = gemv_smem(a.g, pro);
+#define X(n_, l_, p_, q_, hs_, gm_)                                                                                      \
+    if (a.g.n == n_ && sc.L == l_ && pro == p_ && (a.g.q4 != 0) == q_ && t0.head_size == hs_ && (t0.gemma != 0) == gm_)  \
+        return launch_qkv_attn_class<n_, l_, p_, q_, hs_, gm_>(a, grid, gsmem, max_T, wave, s);
+    LMRS_QA_TABLE(X)
+#undef X
+    return hipErrorNotSupported;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1331,14 +1900,6 @@ hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks,
 // Embedding row (transformer.rs:324-332; quantization.rs:25-42) — dequantised on the fly, which is
 // bit-identical to reading the reference's load-time f32 copy of the table.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dequant_elem(const void* q, const float* s, int q4, size_t idx) {     // q4: 0 Q8_0, 1 Q4_0, 2 f32 table (q_type None)
-    if (q4 == 2) return reinterpret_cast<const float*>(q)[idx];
-    if (!q4) return (float)reinterpret_cast<const int8_t*>(q)[idx] * s[idx / kGS];
-    const int8_t v = reinterpret_cast<const int8_t*>(q)[idx >> 1];
-    const int nib = (idx & 1) ? ((v >> 4) & 0x0F) - 8 : (v & 0x0F) - 8;
-    return (float)nib * s[idx / kGS];
-}
-
 __global__ void embed_kernel(const EmbedArgs a) {
     const int pos = a.st->pos;
     const uint32_t token = a.tokens[pos];
@@ -1368,13 +1929,9 @@ hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint
 // sample_argmax (sampler.rs:29-41) over the per-workgroup partials, token feedback, position advance.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a) {
-    __shared__ float sv[kBlock];
-    __shared__ int si[kBlock];
-    __shared__ uint32_t s_next;
     LMRS_STAMP(0);
     if (a.dbg && threadIdx.x == 0) a.dbg[1] = clock64();          // shader-clock cycles, to derive the running clock
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
-    if (threadIdx.x == 0 && a.tail_row > 0) { best = 0.0f; best_i = a.tail_row; }   // the unwritten last rows: 0.0, the first of them wins their tie
     int nan0 = 0;                                                  // index -1: the logit at index 0 is NaN (cls_flag_nan_at_zero)
     // partials: n_groups shards x n_part entries; shard g holds [values | indices] at part_val + g * group_stride
     for (int i = threadIdx.x; i < a.n_part * a.n_groups; i += kBlock) {
@@ -1383,35 +1940,7 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
         if (idx < 0) { nan0 = 1; continue; }
         if (v > best || (v == best && idx < best_i)) { best = v; best_i = idx; }
     }
-    sv[threadIdx.x] = best; si[threadIdx.x] = best_i;
-    nan0 = __syncthreads_or(nan0);
-    for (int off = kBlock / 2; off >= 1; off >>= 1) {
-        if (threadIdx.x < off) {
-            const float ov = sv[threadIdx.x + off]; const int oi = si[threadIdx.x + off];
-            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int win = si[0];
-        if (nan0 || win == 0x7fffffff) win = 0;             // NaN at index 0 is never displaced (strict >); nothing above -inf: index 0
-        const int pos = a.st->pos;
-        uint32_t next = (uint32_t)win;
-        if (pos + 1 >= a.st->prompt_end) a.tokens[pos + 1] = next;   // chat.rs:188-193: sampler output ignored while the prompt lasts
-        else next = a.tokens[pos + 1];
-        a.st->pos = pos + 1;
-        a.st->step_count += 1;
-        s_next = next;
-    }
-    __syncthreads();
-    // embedding row of the next input token (transformer.rs:324-332) for the next replay of the step graph
-    const uint32_t token = s_next;
-    for (int i = threadIdx.x; i < a.emb.dim; i += kBlock) {
-        float v = dequant_elem(a.emb.emb_q, a.emb.emb_s, a.emb.q4, (size_t)token * a.emb.dim + i);
-        if (a.emb.do_scale) v = v * a.emb.scale;
-        a.emb.x[i] = v;
-    }
-    for (int i = threadIdx.x; i < a.n_flag_words; i += kBlock) a.flags[i] = 0u;      // nobody polls between steps
+    argmax_tail(a, best, best_i, nan0, tail_preload(a));
     LMRS_STAMP(3);
     if (a.dbg && threadIdx.x == 0) a.dbg[2] = clock64();
 }
@@ -1621,6 +2150,5 @@ hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s) {
 #include "lmrs_prefill.inc"
 #include "lmrs_f32.inc"        // (its batched kernel uses the epilogues of lmrs_prefill.inc)
 #include "lmrs_vision.inc"
-#include "lmrs_fused.inc"
 
 }  // namespace lmrs

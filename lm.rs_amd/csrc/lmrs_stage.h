@@ -84,12 +84,23 @@ __device__ __forceinline__ void vec_load(float4 (&v)[(VecGeom<N, NTH>::NP)], con
 }
 
 // RMSNorm (reference functional.rs:48-78), in place on v[]; nw[] = norm weights of the same elements.
-// scratch: 8 * (N/8 + 4) + 4 floats of LDS.
+// scratch: rms_scratch_floats(N) floats of LDS.
 // `landed` runs right after the first barrier, i.e. once the activation has arrived (hook for deferred weight loads).
+constexpr int rms_scratch_floats(int n) { return 8 * (n / 8 + 8) + 4; }
+// one 16-byte batch of the chain: this lane's four squares, then the four of the lane 8 above (row_shl:8: the DPP operand of the add
+// itself fetches them - see vec_rmsnorm)
+__device__ __forceinline__ void rms_chain8(float& p, const float4& a) {
+    asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %3\n\tv_add_f32 %0, %0, %4\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_shl:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(p) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+}
 template <int N, int NTH = kBlk, class F = NoHook>
 __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], const float4 (&nw)[(VecGeom<N, NTH>::NP)], float eps, int add_unit, float* scratch,
-                                            unsigned long long* dbg = nullptr, F landed = F()) {
-    constexpr int NP = VecGeom<N, NTH>::NP, JP = N / 8 + 4, NJ4 = N / 32;
+                                            unsigned long long* dbg = nullptr, F landed = F(), const int chain_wave = 0) {
+    constexpr int NP = VecGeom<N, NTH>::NP, JP = N / 8 + 8, NM = N / 64;     // JP % 64 == 8 (or 40): the 16 chain lanes' 16-byte reads hit 16 different bank groups
     static_assert(N % 256 == 0, "N must be a multiple of 256");
     const int t = threadIdx.x;
 #pragma unroll
@@ -106,43 +117,47 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
     lds_barrier();
     landed();
     if (dbg && t == 0) dbg[4] = wall_clock64();          // activation landed, squares in LDS
-    if (t < 64) {
-        // lanes 0..7: the 8 strided partial sums (ss_sim += x*x), each a serial chain of N/8 adds; the LDS
-        // reads run 4 x 16 B ahead of the chain (ping-pong batches).
+    // chain_wave: which wave of the workgroup runs the serial chain.  Launches with two workgroups per CU (w1/w3, the classifier) put
+    // both workgroups' wave 0 on the same SIMD, where the two chains share one instruction issue port: the second workgroup of a CU
+    // (dispatch order b + 256) runs its chain on another wave, i.e. another SIMD.
+    if ((t >> 6) == chain_wave) {
+        // The 8 strided partial sums (ss_sim += x*x) are 8 serial chains of N/8 adds each, in lanes 0..7.  A chain is bound by
+        // instruction issue (one dependent v_add_f32 per 4 cycles), so everything that is NOT an add of the chain is overhead: the
+        // squares are read 16 bytes per lane by SIXTEEN lanes - lane k the values j .. j+3 of chain k, lane 8+k the values j+4 .. j+7
+        // of the same chain - and lane k adds its own four, then the four of lane 8+k through the add's DPP operand (row_shl:8):
+        // 8 adds per LDS read instead of 4, no move instructions.  (Lanes 16..63 repeat lanes 0..15: no divergence, no extra traffic.)
+        // Batches of 4 reads ping-pong so that the next batch is in flight while the current one is added.
         float p = 0.0f;
-        if (t < 8) {
-            const float4* row = reinterpret_cast<const float4*>(scratch + t * JP);
-            // The adds are one serial chain; the LDS reads are not.  Two batches of 8 x 16 B ping-pong, with compiler
-            // barriers so that the next batch's reads are ISSUED before the current batch's 32 adds (left alone, the
-            // scheduler sinks the reads next to their uses and exposes the LDS latency once per 16 adds).
-            constexpr int BF = 8, NB = NJ4 / BF;               // batches of 8 x 16 B (32 adds each)
-            static_assert(NJ4 % BF == 0, "row length must be a multiple of 32 floats");
-            float4 A[BF], B[BF];
+        const int cl = t & 15;
+        const float4* row = reinterpret_cast<const float4*>(scratch + (cl & 7) * JP) + (cl >> 3);     // float4 2m + (cl >> 3) = values 8m + 4 (cl >> 3) ..
+        constexpr int BF = 4, NB = NM / BF;
+        static_assert(NM % BF == 0, "row length must be a multiple of 32 values");
+        float4 A[BF], B[BF];
 #pragma unroll
-            for (int u = 0; u < BF; ++u) A[u] = row[u];
+        for (int u = 0; u < BF; ++u) A[u] = row[2 * u];
 #pragma unroll
-            for (int b0 = 0; b0 < NB; b0 += 2) {
-                if (b0 + 1 < NB) {
+        for (int b0 = 0; b0 < NB; b0 += 2) {
+            if (b0 + 1 < NB) {
 #pragma unroll
-                    for (int u = 0; u < BF; ++u) B[u] = row[(b0 + 1) * BF + u];
+                for (int u = 0; u < BF; ++u) B[u] = row[2 * ((b0 + 1) * BF + u)];
+            }
+            asm volatile("" ::: "memory");                       // the reads above are issued before the adds below
+#pragma unroll
+            for (int u = 0; u < BF; ++u) rms_chain8(p, A[u]);
+            if (b0 + 1 < NB) {
+                if (b0 + 2 < NB) {
+#pragma unroll
+                    for (int u = 0; u < BF; ++u) A[u] = row[2 * ((b0 + 2) * BF + u)];
                 }
-                asm volatile("" : "+v"(p) : : "memory");         // the running sum passes through: the adds below cannot move above the reads
+                asm volatile("" ::: "memory");
 #pragma unroll
-                for (int u = 0; u < BF; ++u) { p = p + A[u].x; p = p + A[u].y; p = p + A[u].z; p = p + A[u].w; }
-                if (b0 + 1 < NB) {
-                    if (b0 + 2 < NB) {
-#pragma unroll
-                        for (int u = 0; u < BF; ++u) A[u] = row[(b0 + 2) * BF + u];
-                    }
-                    asm volatile("" : "+v"(p) : : "memory");
-#pragma unroll
-                    for (int u = 0; u < BF; ++u) { p = p + B[u].x; p = p + B[u].y; p = p + B[u].z; p = p + B[u].w; }
-                }
+                for (int u = 0; u < BF; ++u) rms_chain8(p, B[u]);
             }
         }
-        const float p0 = __shfl(p, 0), p1 = __shfl(p, 1), p2 = __shfl(p, 2), p3 = __shfl(p, 3);
-        const float p4 = __shfl(p, 4), p5 = __shfl(p, 5), p6 = __shfl(p, 6), p7 = __shfl(p, 7);
-        if (t == 0) {
+        const int wl = t & 48;                               // lanes 0..7 of this lane's own row hold the chains' sums
+        const float p0 = __shfl(p, wl + 0), p1 = __shfl(p, wl + 1), p2 = __shfl(p, wl + 2), p3 = __shfl(p, wl + 3);
+        const float p4 = __shfl(p, wl + 4), p5 = __shfl(p, wl + 5), p6 = __shfl(p, wl + 6), p7 = __shfl(p, wl + 7);
+        if ((t & 63) == 0) {
             float ss = reduce_add8(p0, p1, p2, p3, p4, p5, p6, p7);
             ss = ss / (float)N;
             ss = ss + eps;

@@ -632,18 +632,37 @@ def test_rccl_path_with_one_rank(L):
         assert_bit_equal(m.forward(int(t), pos), o2.forward(int(t), pos), f"rccl world=1 logits at pos {pos}")
 
 
-def test_fused_attention_block_in_launch_sync(L, monkeypatch):
-    """LMRS_FUSED=1: qkv -> attention -> wo of a layer as ONE launch whose phases are separated by in-launch arrival
-    counters and agent-scope (write-through / L1-bypassing) exchanges instead of kernel boundaries.  Must be bit-identical."""
-    monkeypatch.setenv("LMRS_FUSED", "1")
-    img = S.build_image("mini-llama", S.Q8_0, seed=41)
-    m = L.Transformer(img); orc = O.Oracle(img)
-    assert m.step_info(0)[0] == 3 * 2 + 2            # 3 launches per layer instead of 5
-    prompt = S.prompt_tokens("mini-llama", 6, 41)
-    assert (m.generate_greedy(prompt, 40) == orc.generate_greedy(prompt, 40)).all()
-    o2 = O.Oracle(img); m2 = L.Transformer(img)
-    for pos, t in enumerate(prompt):
-        assert_bit_equal(m2.forward(int(t), pos), o2.forward(int(t), pos), f"fused logits at pos {pos}")
+@pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q8_0), ("mini-llama3b", S.Q8_0), ("mini-phi", S.Q8_0), ("mini-gemma", S.Q8_0),
+                                   ("mini-gemma", S.Q4_0), ("mini-llama", S.Q4_0)])
+def test_merged_qkv_attention_launch_and_classifier_tail(L, monkeypatch, cfg, q):
+    """The decode step's in-launch hand-offs: qkv + attention as ONE launch (the attention workgroups poll the {value, tag}
+    granules the GEMV workgroups of the same launch write; one wave per head at the shortest contexts, one workgroup per head
+    after that) and the final argmax folded into the classifier launch (workgroup 0 sweeps the tagged partials).  All forms -
+    default, workgroup form only, everything as separate launches - must give the CPU path's token ids over a run that crosses
+    the wave -> workgroup switch, and bit-equal logits when positions are re-run out of order (the tags come from a step counter
+    that never repeats, not from the position)."""
+    img = S.build_image(cfg, q, seed=41)
+    orc = O.Oracle(img)
+    prompt = S.prompt_tokens(cfg, 6, 41)
+    n_new = 150
+    ref = orc.generate_greedy(prompt, n_new)
+    m = L.Transformer(img)
+    nl = m.args.n_layers
+    merged = m.step_info(0)[0] == 4 * nl + 1
+    assert merged, f"{cfg}: the merged launch is not in use ({m.step_info(0)[0]} launches per step)"
+    assert (m.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: default form"
+    monkeypatch.setenv("LMRS_QKV_ATT", "1")                  # one workgroup per head from position 0
+    m1 = L.Transformer(img)
+    assert (m1.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: workgroup form"
+    monkeypatch.setenv("LMRS_QKV_ATT", "0"); monkeypatch.setenv("LMRS_CLS_TAIL", "0")
+    m0 = L.Transformer(img)
+    assert m0.step_info(0)[0] == 5 * nl + 2
+    assert (m0.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: separate launches"
+    # positions re-run out of order on the default form (cache rows of the run above are in place): logits bit for bit
+    toks = np.concatenate([prompt, ref]).astype(np.uint32)
+    for pos in (3, 70, 3, 64, 63, 127, 128, 5, 140):
+        assert_bit_equal(m.forward(int(toks[pos]), pos), orc.forward(int(toks[pos]), pos), f"{cfg} logits at re-run pos {pos}")
+        assert m.forward_argmax(int(toks[pos]), pos) == int(toks[pos + 1]) or pos < len(prompt) - 1
 
 
 # ------------------------------------------------------------------ error behaviour (reference: panics)

@@ -20,12 +20,11 @@ toks, sec = m.generate_greedy(prompt, npos - 15, timing=True)
 print(f"{(16 + npos - 16) / sec:.0f} tok/s over {npos} steps")
 tl = m.debug_timeline().astype(np.int64)
 names = ["qkv", "attn", "wo", "w13", "w2"]
-if os.environ.get("LMRS_FUSED"):
-    names = ["fusedA", "w13", "w2"]
 NK = len(names)
 t0 = tl[0, 0]
 print("node  name   start  | first WG: pro   pass1  end   | last WG: start pro pass1 end | gap_to_next   (us, 10ns clock)")
-L = (len(tl) - 2) // NK
+TAIL = 1 if (len(tl) - 1) % NK == 0 else 2          # 1: the final argmax is folded into the classifier launch (no node of its own)
+L = (len(tl) - TAIL) // NK
 tot = {}
 for i, r in enumerate(tl):
     name = names[i % NK] if i < NK * L else ("cls" if i == NK * L else "argmax")
@@ -45,6 +44,15 @@ att = tl[1::5][:L] if NK == 5 else tl[0::NK][:L]
 d = (att - att[:, :1]) / 100.0
 print("attention block0 stamps (us from start): rope-inputs-issued, rope-done, scores-done, softmax-done, v-in-lds, end")
 print("   ", np.round(d[:, [1, 2, 4, 5, 6, 7]].mean(axis=0), 2))
+if NK == 5:
+    # merged qkv + attention launch: the attention node's stamps belong to head 0's workgroup of the SAME launch as the qkv node
+    q0 = tl[0::5][:L][:, :1]
+    dm = (att - q0) / 100.0
+    print("merged launch, head 0 (us from the qkv node's start; workgroup form: -, polled, rope, -, scores, softmax, v-in-lds, end;")
+    print("   wave form: start, prefetch issued, polled, rope, scores, softmax, -, end)")
+    print("   ", np.round(dm.mean(axis=0), 2))
+    qk = tl[0::5][:L]
+    print("   qkv first workgroup end:", np.round(((qk[:, 3] - qk[:, 0]) / 100.0).mean(), 2), " last workgroup end:", np.round(((qk[:, 7] - qk[:, 0]) / 100.0).mean(), 2))
 for nm, off in (("wo", 2), ("w2", 4)):
     if NK == 5:
         g = tl[off::5][:L]; d = (g - g[:, :1]) / 100.0
@@ -54,5 +62,9 @@ for nm, off in (("qkv", 0), ("w13", 3)):
         g = tl[off::5][:L]; d = (g - g[:, :1]) / 100.0
         print(f"{nm} block0 (us from start): x landed+squares {d[:,4].mean():.2f}  chain done {d[:,5].mean():.2f}  quantised {d[:,1].mean():.2f}  rows done {d[:,2].mean():.2f}  end {d[:,3].mean():.2f}")
 am = tl[-1]
-print(f"shader clock during argmax kernel: {(am[2]-am[1]) / ((am[3]-am[0]) / 100.0):.0f} MHz")
+if TAIL == 1:
+    print("classifier launch (us from its start): first GEMV workgroup prologue / first pass / end:", np.round((am[1:4] - am[0]) / 100.0, 2),
+          " consumer workgroup start / all partials seen / end:", np.round((am[[4, 5, 7]] - am[0]) / 100.0, 2))
+if TAIL == 2:
+    print(f"shader clock during argmax kernel: {(am[2]-am[1]) / ((am[3]-am[0]) / 100.0):.0f} MHz")
 print(f"step span: {(max(tl[-1,3], tl[-1,7]) - t0)/100.0:.1f} us")

@@ -154,6 +154,9 @@ int lmrs_op_classifier_argmax(int device, const float* x, const float* rms_w, co
                               float eps, uint32_t* token, float* logits);
 /* f32::exp as used by softmax (functional.rs:133) and SiLU (transformer.rs:617): the device's bit-exact restatement of glibc expf. */
 int lmrs_op_expf(int device, float* y, const float* x, size_t n);
+/* y = (float)tanh(c * (double)x): f64::tanh as the reference calls it for Gemma's soft-caps (transformer.rs:520-522, 377-379; c = 1) and
+ * the tanh-GELU (transformer.rs:614; c = 0.7978845608028654) - the device's f64 tanh, for comparison with the host libm (oracle/tanh_check.c). */
+int lmrs_op_tanh_cast(int device, float* y, const float* x, size_t n, double c);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------
  * Runs, `iters` times, the dequant-GEMV launches of ONE decode step in step order (per layer: qkv, wo,

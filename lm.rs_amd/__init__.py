@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
@@ -92,6 +92,7 @@ def lib():
         L.lmrs_op_rmsnorm.argtypes = [C.c_int, vp, vp, vp, sz, C.c_float, C.c_int]
         L.lmrs_op_softmax.argtypes = [C.c_int, vp, sz]
         L.lmrs_op_expf.argtypes = [C.c_int, vp, vp, sz]
+        L.lmrs_op_tanh_cast.argtypes = [C.c_int, vp, vp, sz, C.c_double]
         L.lmrs_bench_gemv.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.lmrs_step_info.argtypes = [vp, u32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.lmrs_debug_timeline.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
@@ -339,6 +340,14 @@ def expf(x, device=0):
     x = np.ascontiguousarray(x, np.float32)
     y = np.empty_like(x)
     _chk(lib().lmrs_op_expf(device, _p(y), _p(x), x.size))
+    return y
+
+
+def tanh_cast(x, c=1.0, device=0):
+    """(float)tanh(c * (double)x) as the kernels evaluate it (Gemma soft-caps: c = 1; tanh-GELU: c = 0.7978845608028654)"""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    _chk(lib().lmrs_op_tanh_cast(device, _p(y), _p(x), x.size, float(c)))
     return y
 
 

@@ -125,14 +125,16 @@ hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hip
 hipError_t launch_rmsnorm(const float* x, const float* w, float* o, int n, float eps, int add_unit, hipStream_t st);
 hipError_t launch_softmax(float* x, int n, hipStream_t st);
 hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st);
+hipError_t launch_tanh_cast(const float* x, float* y, size_t n, double c, hipStream_t st);   // y = (float)tanh(c * (double)x)
 
 constexpr int kMaxArgmaxParts = 4096;
 
 // ---- peer-to-peer exchange of the row-sharded step (exchange_push_kernel)
+constexpr int kMaxWorld = 8;              // shards of a peer-to-peer group: the GPUs of one node (sizes every per-peer array and the flag rows)
 struct ExchangeArgs {
     const char* local;            // my block in my arena
-    char* peer_dst[8];            // the same place in every peer's arena
-    unsigned* peer_flag[8];       // my flag word in every peer's flag row of this slot
+    char* peer_dst[kMaxWorld];            // the same place in every peer's arena
+    unsigned* peer_flag[kMaxWorld];       // my flag word in every peer's flag row of this slot
     unsigned* my_flags;           // my flag row of this slot (one word per source shard)
     unsigned* my_seq; int* err;
     int bytes, rank, world, slot; long long timeout_ticks;

@@ -2088,6 +2088,17 @@ __global__ void expf_kernel(const float* x, float* y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = expf_glibc(x[i]);
 }
 
+// (float)tanh(c * (double)x): the f64 tanh of Gemma's score / logit soft-caps (c = 1: transformer.rs:520-522, 377-379, after the f32
+// division by the cap) and of the tanh-GELU (c = 0.7978845608028654 on the f32 cubic: transformer.rs:614) exactly as the kernels
+// evaluate it (ocml's f64 tanh, rounded to f32) - exported so that it can be compared with the host libm the reference calls.
+__global__ void tanh_cast_kernel(const float* x, float* y, size_t n, double c) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)tanh(c * (double)x[i]);
+}
+hipError_t launch_tanh_cast(const float* x, float* y, size_t n, double c, hipStream_t st) {
+    hipLaunchKernelGGL(tanh_cast_kernel, dim3(1024), dim3(256), 0, st, x, y, n, c);
+    return hipGetLastError();
+}
+
 hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(expf_kernel, dim3(1024), dim3(256), 0, st, x, y, n);
     return hipGetLastError();

@@ -3,10 +3,10 @@
 //   Sampler    reference src/sampler.rs: new :19-27, sample :109-129 (argmax :29-41, sample_mult :43-55, sample_topp :67-106),
 //              with random_f32 / random_u32 of src/functional.rs:34-44
 // Both are HOST code on purpose, bit for bit what the reference computes:
-//   * the sampler's softmax (functional.rs:122-140) is one sequential chain of vocab_size additions; a GPU lane runs such a
-//     chain at ~4 cycles per add - for 128 256 logits longer than the whole decode step - while the host does it in ~0.1 ms
-//     from lmrs_forward's pinned logits.  Greedy decoding (temperature 0) never comes here: the argmax is fused into the
-//     classifier launch on the device.
+//   * the sampler's softmax (functional.rs:122-140) and sample_mult's running cdf (sampler.rs:43-55) are two sequential chains of
+//     vocab_size additions; a GPU lane runs such a chain at ~4 cycles per add (2 x 0.21 ms for 128 256 logits, against a 0.44 ms
+//     decode step), the host in ~0.1 ms from lmrs_forward's pinned logits (DESIGN.md section 7 has both numbers measured).  Greedy
+//     decoding (temperature 0) never comes here: the argmax is fused into the classifier launch on the device.
 //   * the tokenizer is string work.
 // No GPU is needed for anything in this file (the -m "not gpu" tests exercise it).  Compiled with -ffp-contract=off like
 // the rest of the library; expf is the host libm's, which is what Rust's f32::exp calls.
@@ -98,7 +98,10 @@ extern "C" int lmrs_tokenizer_create(const uint8_t* data, size_t len, lmrs_token
     if (!data || !out) return text_fail("NULL argument");
     *out = nullptr;
     if (len < 16) return text_fail("tokenizer file shorter than its 16-byte header");
-    auto* t = new lmrs_tokenizer();
+    if (rd_u32(data) > (len - 16) / 8) return text_fail("tokenizer file truncated");           // every entry is at least a score and a length: no allocation from an unchecked header
+    lmrs_tokenizer* t = nullptr;
+    try {
+    t = new lmrs_tokenizer();
     t->vocab_size = rd_u32(data); t->bos = rd_u32(data + 8); t->eos = rd_u32(data + 12);      // [4..8) = max_token_len, unused (:28)
     size_t off = 16;
     t->vocab.reserve(t->vocab_size); t->scores.reserve(t->vocab_size);
@@ -114,6 +117,7 @@ extern "C" int lmrs_tokenizer_create(const uint8_t* data, size_t len, lmrs_token
     t->bsearch_flavour = fl ? atoi(fl) : 0;
     *out = t;
     return 0;
+    } catch (...) { delete t; return text_fail("out of memory while reading the tokenizer file"); }   // nothing may unwind through the C ABI
 }
 
 extern "C" void lmrs_tokenizer_destroy(lmrs_tokenizer* t) { delete t; }
@@ -128,8 +132,15 @@ extern "C" int lmrs_tokenizer_info(const lmrs_tokenizer* t, uint32_t* vocab_size
 
 // Tokenizer::encode (tokenizer.rs:66-151).  model_type: 0 GEMMA, 1 LLAMA, 2 PHI.  *n = number of ids; if it exceeds `cap`
 // nothing is written beyond cap and the call fails (call again with a larger buffer: n <= bytes of text + 16).
+static int tokenizer_encode_impl(lmrs_tokenizer* t, const char* text, size_t text_len, int bos, int eos, int chat_format, int model_type,
+                                 uint32_t* out, size_t cap, size_t* n);
 extern "C" int lmrs_tokenizer_encode(lmrs_tokenizer* t, const char* text, size_t text_len, int bos, int eos, int chat_format, int model_type,
                                      uint32_t* out, size_t cap, size_t* n) {
+    try { return tokenizer_encode_impl(t, text, text_len, bos, eos, chat_format, model_type, out, cap, n); }
+    catch (...) { return text_fail("out of memory while encoding"); }                                // nothing may unwind through the C ABI
+}
+static int tokenizer_encode_impl(lmrs_tokenizer* t, const char* text, size_t text_len, int bos, int eos, int chat_format, int model_type,
+                                 uint32_t* out, size_t cap, size_t* n) {
     if (!t || !text || !n) return text_fail("NULL argument");
     if (text_len == 0) return text_fail("Text to encode should not be empty");
     if (!valid_utf8(reinterpret_cast<const uint8_t*>(text), text_len)) return text_fail("text is not valid UTF-8 (the reference takes a &str)");
@@ -222,9 +233,12 @@ extern "C" int lmrs_sampler_create(uint32_t vocab_size, float temperature, float
     if (!out) return text_fail("NULL argument");
     *out = nullptr;
     if (vocab_size == 0) return text_fail("vocab_size must be positive");
-    auto* s = new lmrs_sampler();
-    s->vocab_size = vocab_size; s->temperature = temperature; s->top_p = top_p; s->seed = seed;
-    s->probindex.assign(vocab_size, {0.0f, 0u});
+    lmrs_sampler* s = nullptr;
+    try {
+        s = new lmrs_sampler();
+        s->vocab_size = vocab_size; s->temperature = temperature; s->top_p = top_p; s->seed = seed;
+        s->probindex.assign(vocab_size, {0.0f, 0u});
+    } catch (...) { delete s; return text_fail("out of memory (sampler candidates)"); }                // nothing may unwind through the C ABI
     *out = s;
     return 0;
 }

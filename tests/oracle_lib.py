@@ -55,6 +55,7 @@ def lib():
         L.lmrs_ref_op_quantize.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize.restype = None
         L.lmrs_ref_op_quantize_q4.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize_q4.restype = None
         L.lmrs_ref_op_expf.argtypes = [C.c_float]; L.lmrs_ref_op_expf.restype = C.c_float
+        L.lmrs_ref_op_tanh_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double]; L.lmrs_ref_op_tanh_cast.restype = None
         L.lmrs_ref_rope_terms.argtypes = [C.POINTER(Args), u32, u32, f32p, f32p]; L.lmrs_ref_rope_terms.restype = None
         _lib = L
     return _lib
@@ -162,6 +163,14 @@ def matmul_q4(xq, xs, wq, ws, n, o, gs=128):
 
 def expf(x: float) -> float:
     return lib().lmrs_ref_op_expf(float(x))
+
+
+def tanh_cast(x, c=1.0) -> np.ndarray:
+    """(float)tanh(c * (double)x) with the host libm (numpy's own tanh is a SIMD implementation, not libm's)"""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().lmrs_ref_op_tanh_cast(_p(x), _p(y), x.size, float(c))
+    return y
 
 
 def threads() -> int:

@@ -46,6 +46,22 @@ def test_expf_matches_host_libm(L):
     assert_bit_equal(dev[1 << 20: (1 << 20) + (1 << 16)], np.array([O.expf(float(v)) for v in mid], np.float32), "expf wide range")
 
 
+@pytest.mark.parametrize("c", [1.0, 0.7978845608028654])
+def test_tanh_matches_host_libm(L, c):
+    """f64::tanh (Gemma's score / logit soft-caps, c = 1; the tanh-GELU, c = 0.79788...) is the one transcendental the device does
+    not restate: it calls ocml's f64 tanh and rounds to f32, the reference calls the host libm.  Swept here over every f32 in four
+    binades around 1 where tanh bends (|x| in [0.25, 4): 2 x 33.5 M inputs), every 61st f32 of the whole line, and the edges."""
+    band = np.arange(np.float32(0.25).view(np.uint32), np.float32(4.0).view(np.uint32), dtype=np.uint32).view(np.float32)
+    line = np.arange(0, 0x7f800000, 61, dtype=np.uint32).view(np.float32)
+    edges = np.array([0.0, -0.0, 1e-40, -1e-40, 1e-8, 19.0, 19.06, 19.1, 20.0, 30.0, 88.0, 1e30, np.inf, -np.inf, np.nan], np.float32)
+    for xs in (band, -band, line, -line, edges):
+        dev = L.tanh_cast(xs, c)
+        host = O.tanh_cast(xs, c)
+        ne = np.flatnonzero(bits(dev) != bits(host))
+        ne = ne[~(np.isnan(dev[ne]) & np.isnan(host[ne]))]
+        assert ne.size == 0, f"tanh(c={c}): {ne.size}/{xs.size} inputs differ, first x = {xs[ne[:5]]}: device {dev[ne[:5]]} host {host[ne[:5]]}"
+
+
 @pytest.mark.parametrize("n", [128, 256, 2048, 3072, 8192, 9216])
 def test_quantize(L, n):
     rng = np.random.default_rng(n)
@@ -680,6 +696,10 @@ def test_errors(L):
         m.forward(0, m.args.seq_len)
     with pytest.raises(L.LmrsError):
         m.generate_greedy(np.zeros(0, np.uint32), 4)
+    # the peer-to-peer transport's per-peer tables hold 8 shards (one node): a larger world without a communicator id is refused at create
+    # (tiny_llama's vocabulary of 256 rows divides by 16, so the "cls" plan itself would have accepted it)
+    with pytest.raises(L.LmrsError, match="at most 8 shards"):
+        L.Transformer(img, rank=1, world=16)
     # Phi with a head size above 96: the reference indexes past its 48 LongRoPE factors and panics (transformer.rs:473-475)
     phi128 = S.build_image(S.ModelCfg("phi-128", 128, 128, 1, 2, 128, 2, 256, 32, 1e-5, 10000.0, S.PHI), S.Q8_0, seed=3, threads=1)
     with pytest.raises(L.LmrsError, match="LongRoPE"):

@@ -86,6 +86,24 @@ def pmc_traffic(model, qtype):
     return None
 
 
+def rocprof_family_us(model, qtype):
+    """Time of the dequant-GEMV family per decode step priced with rocprofv3's per-kernel averages (profiles/*_rocprof_*.json, made by
+    tools/rocprof_summary.py from `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-steps 0`), for THIS model, quantisation
+    and build of the kernels; None otherwise."""
+    want = (model, qtype, kernel_source_hash())
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if "_rocprof_" not in f or not f.endswith(".json"):
+            continue
+        try:
+            doc = json.load(open(os.path.join(pdir, f)))
+            if (doc.get("model"), doc.get("qtype"), doc.get("kernel_source_hash")) == want:
+                return float(doc["gemv_family_us_per_step"])
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def shard_description(lmrs_amd, model, world, transport):
     """Which matrices the library split for this model and world size (lmrs_shard_plan: it row-splits the layers' matrices only when
     the stream a shard stops reading outweighs two exchanges per layer; below that every GPU runs the layers whole and only the
@@ -116,6 +134,7 @@ def main():
     ap.add_argument("--qtype", default="q8_0", choices=["q8_0", "q4_0"], help="weight quantisation of the synthetic image (config 3: gemma-2-2b q4_0)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps for cpu_baseline (-1: same as the GPU run, 0: skip)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--vision", action="store_true", help="BASELINE configs[4] (use with --model phi-3.5): add a `vision` object - CLIP tower, projector, fill_kv_cache(320)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,180 +194,257 @@ def main():
     prompt = S.prompt_tokens(cfg, W, 1234)
     t_build = time.time() - t0
 
-    # N > 1: ONE decode stream, weight matrices row-split over the N GPUs (one process per GPU), RCCL all-gathers
-    # of the per-shard slices over xGMI between the fused kernels.  Token ids stay identical.
-    sharded = dist is not None
-    transport = None
-    if sharded:
-        # Transport of the per-layer exchanges (a few KB each, latency-bound): peer-to-peer pushes over xGMI by default (a store + flag
-        # kernel per exchange, arenas opened through IPC handles; lmrs_p2p_connect ends with a handshake), RCCL all-gathers if any rank
-        # cannot connect (or LMRS_BENCH_TRANSPORT=rccl).  With a world of one (LMRS_BENCH_FORCE_DIST) only the RCCL path exists.
-        want = os.environ.get("LMRS_BENCH_TRANSPORT", "p2p" if world > 1 else "rccl")
-        model = None
-        if want == "p2p":
-            ok = 1
-            try:
-                model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world)
-                handles = [None] * world
-                dist.all_gather_object(handles, model.p2p_handle())
-                model.p2p_connect(handles)
-            except Exception as e:                      # noqa: BLE001 - any failure means: fall back, together
-                print(f"[rank {rank}] peer-to-peer transport unavailable: {e}", file=sys.stderr)
-                ok = 0
-            if all_ranks_ok(ok == 1):
-                transport = "p2p"
-            else:
-                if model is not None:
-                    model.close()
-                model = None
-        if model is None:
-            uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
-            model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
-            transport = "rccl"
-    else:
-        model = lmrs_amd.Transformer(img, device=local_rank)
-
-    def timed_run(model):
-        # ---- warm-up: the W prompt tokens (token by token, as the reference feeds prompts), untimed
-        first = model.generate_greedy(prompt, 1)
-        device_sync(); barrier()
-        # ---- timed: exactly K decode steps at positions W .. W+K-1
-        t1 = time.perf_counter()
-        toks, dev_sec = model.generate_greedy(first, K, start_pos=W, timing=True)
-        device_sync(); barrier()
-        t2 = time.perf_counter()
-        return first, toks, dev_sec, t2 - t1
-
-    if transport == "p2p":
-        # a peer-to-peer exchange that times out mid-run (bounded wait, sticky error) must not cost the job its result: every rank
-        # reports, and if any of them failed all of them redo the run over RCCL
-        res = None
-        try:
-            res = timed_run(model)
-        except Exception as e:                          # noqa: BLE001
-            print(f"[rank {rank}] peer-to-peer run failed: {e}", file=sys.stderr)
-        if not all_ranks_ok(res is not None):
-            model.close()
-            uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
-            model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
-            transport = "rccl (peer-to-peer run failed)"
-            res = timed_run(model)
-    else:
-        res = timed_run(model)
-    first, toks, dev_sec, wall = res
-    elapsed = max_over_ranks(dist, wall, ("cpu" if dist.get_backend() == "gloo" else "cuda") if dist is not None else None)
-    gen = np.concatenate([first, toks])[: K + 1]          # token ids produced after positions W-1 .. W+K-1
-    shard_steps = None
-    if sharded:
-        # per-kernel / per-exchange durations inside the sharded step (every rank takes part: the exchanges wait for the peers)
-        try:
-            shard_steps = model.bench_step(W + K, 8)
-        except Exception as e:                          # noqa: BLE001
-            print(f"[rank {rank}] bench_step: {e}", file=sys.stderr)
-        barrier()
-
-    out = None
-    if rank == 0:
-        tok_s = K / elapsed                      # one decode stream, whatever the number of GPUs
-        # whole-path bytes over the timed positions
-        path_bytes = sum(model.step_info(p)[1] for p in range(W, W + K))
-        n_launch = model.step_info(W)[0]
-        # ---- dominant kernel: per-shape live timing with HIP events
-        path = {"bytes_per_step": round(path_bytes / K), "us_per_step": round(elapsed / K * 1e6, 2),
-                "achieved": round(path_bytes / elapsed / 1e9, 1), "frac": round(path_bytes / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
-                "kernel_launches_per_step": n_launch, "device_event_us_per_step": round(dev_sec / K * 1e6, 2)}
+    def run_once(plan=None, transport_override=None):
+        """One configuration of the job: build the context(s), warm up, time K steps, report.  plan: None = the library's own choice
+        (LMRS_SHARD_PLAN if the caller set it), "tp" / "cls" = forced for this run; transport_override: "rccl" / "p2p"."""
+        if plan is not None:
+            os.environ["LMRS_SHARD_PLAN"] = plan
+        # N > 1: ONE decode stream, weight matrices row-split over the N GPUs (one process per GPU), RCCL all-gathers
+        # of the per-shard slices over xGMI between the fused kernels (SURVEY.md §8e).  Token ids stay identical.
+        sharded = dist is not None
+        transport = None
         if sharded:
-            # where a sharded step goes - streaming kernels, glue, exchanges, and what is left (launch gaps)
-            split = None
-            if shard_steps:
-                iters = 8
-                per = {k: {"us": round(us / n, 3), "launches_per_step": n // iters} for k, (us, _b, n) in shard_steps.items()}
-                stream_us = sum(us for k, (us, _b, n) in shard_steps.items() if k not in ("exchange", "glue")) / iters
-                glue_us = shard_steps.get("glue", (0.0, 0, 0))[0] / iters
-                ex_us = shard_steps.get("exchange", (0.0, 0, 0))[0] / iters
-                gemv_b = sum(_b for k, (us, _b, n) in shard_steps.items() if k in ("qkv", "wo", "w1w3", "w2", "classifier")) / iters
-                gemv_us = sum(us for k, (us, _b, n) in shard_steps.items() if k in ("qkv", "wo", "w1w3", "w2", "classifier")) / iters
-                split = {"stream_us": round(stream_us, 2), "glue_us": round(glue_us, 2),
-                         "exchange_us": round(ex_us, 2) if transport == "p2p" else None,
-                         "gap_us": round(elapsed / K * 1e6 - stream_us - glue_us - (ex_us if transport == "p2p" else 0.0), 2),
-                         "gemv_GBps_this_rank": round(gemv_b / gemv_us / 1e3, 1) if gemv_us else None, "kernels": per,
-                         "note": "rank 0's eager replay of the real step with an event pair per dispatch; a dispatch's duration includes its launch boundary; "
-                                 "exchange_us includes waiting for the slowest peer; with RCCL the collectives carry no events and sit in gap_us"}
-            roofline = {"bound": "hbm", "kernel": "whole sharded step", "achieved": path["achieved"],
-                        "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": path["frac"], "traffic": None, "path": path,
-                        "transport": transport, "sharded_step_is_one_hipgraph": model.shard_uses_graph(), "step_split": split}
-        else:
-          # the real step, replayed eagerly from the live state with an event pair on every dispatch: each kernel's
-          # duration as it runs inside the step (real predecessor, real activations, positions W+K+1 ...)
-          iters = 8
-          res = model.bench_step(W + K, iters)
-          per, tot_us, tot_b, n_gemv, step_us = {}, 0.0, 0.0, 0, 0.0
-          for name, (us, b, n) in res.items():
-            per[name] = {"us": round(us / n, 3), "MB": round(b / n / 1e6, 3), "GBps": round(b / us / 1e3, 1), "launches_per_step": n // iters}
-            step_us += us / iters
-            if name not in ("attention", "argmax"):
-              tot_us += us / iters; tot_b += b / iters; n_gemv += n // iters
-          achieved = tot_b / tot_us / 1e3            # GB/s
-          roofline = {
-            "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel (fused dequant-GEMV, all shapes of one step), durations taken inside the real step",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "frac_vs_measured_copy": round(achieved / MEASURED_COPY_GBPS, 4),
-            "traffic": pmc_traffic(cfg.name, args.qtype),
-            "bytes_per_launch_avg": round(tot_b / n_gemv), "avg_launch_us": round(tot_us / n_gemv, 3), "launches_per_step": n_gemv,
-            "in_step": per, "sum_of_kernel_us_per_step": round(step_us, 2), "kernel_source_hash": kernel_source_hash(),
-            "path": path,
-          }
-        # ---- CPU baseline + parity gate
-        cpu = None; parity = None
-        cpu_steps = K if args.cpu_steps < 0 else args.cpu_steps
-        if cpu_steps > 0:
-            import oracle_lib as O
-            if args.cpu_threads > 0:
-                os.environ["LMRS_REF_THREADS"] = str(args.cpu_threads)
-            elif "LMRS_REF_THREADS" not in os.environ:
-                # the team the host can really run: affinity mask capped by the container's CPU quota (OpenMP sees only the former,
-                # and 16 spinning threads on a 2-CPU quota are an order of magnitude slower than 2)
-                budget = len(os.sched_getaffinity(0))
+            # Transport of the per-layer exchanges (a few KB each, latency-bound): peer-to-peer pushes over xGMI by default (a store + flag
+            # kernel per exchange, arenas opened through IPC handles; lmrs_p2p_connect ends with a handshake), RCCL all-gathers if any rank
+            # cannot connect (or LMRS_BENCH_TRANSPORT=rccl).  With a world of one (LMRS_BENCH_FORCE_DIST) only the RCCL path exists.
+            want = transport_override or os.environ.get("LMRS_BENCH_TRANSPORT", "p2p" if world > 1 else "rccl")
+            model = None
+            if want == "p2p":
+                ok = 1
                 try:
-                    quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-                    if quota != "max":
-                        budget = min(budget, max(1, int(quota) // int(period)))
-                except (OSError, ValueError):
-                    pass
-                os.environ["LMRS_REF_THREADS"] = str(min(16, budget))
-            orc = O.Oracle(img)
-            n_new = min(cpu_steps, K) + 1
-            ref, sec = orc.generate_greedy(prompt, n_new, timing=True)
-            steps_run = W + n_new - 1
-            cpu = {"value": round(steps_run / sec, 2), "unit": "tok/s", "cores": O.threads(), "kind": "port",
-                   "sample": f"same image and prompt: {W} prompt + {n_new - 1} greedy steps in {sec:.2f}s, OpenMP over rows/heads"}
-            parity = {"tokens_compared": int(n_new), "tokens_equal": bool((ref == gen[:n_new]).all())}
-        # ---- batched forward_layer (fill_kv_cache): the path's only dense contraction, int8 MFMA
-        prefill = None
-        if not sharded and args.qtype == "q8_0" and cfg.model_type != S.GEMMA:
-            n_pf = 256
-            emb = model.get_embeddings(S.prompt_tokens(cfg, n_pf, 4321))
-            best = 1e9
-            for _ in range(2):
-                e = emb.copy()
-                t_a = time.perf_counter(); model.fill_kv_cache(e, 0); best = min(best, time.perf_counter() - t_a)
-            att = cfg.n_heads * cfg.head_size; kvd = cfg.n_kv_heads * cfg.head_size
-            macs = n_pf * cfg.n_layers * (cfg.dim * (att + 2 * kvd) + att * cfg.dim + 3 * cfg.dim * cfg.hidden_dim)
-            prefill = {"tokens": n_pf, "ms": round(best * 1e3, 2), "tok_s": round(n_pf / best, 1), "achieved": round(2 * macs / best / 1e12, 1),
-                       "peak": 3944.0, "unit": "int8 TOP/s", "bound": "mfma", "frac": round(2 * macs / best / 1e12 / 3944.0, 4),
-                       "kernel": "lmrs::gemm_q8_kernel (v_mfma_i32_16x16x64_i8) + per-token rows, host<->device copies of the embeddings included"}
-        out = {
-            "metric": "decode tok/s + %HBM-roofline, Llama-3.2-1B Q8_0 @1/2/4/8 MI355X vs CPU ref",
-            "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
-            "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine" if args.qtype == "q8_0" else "int4xint4->int32, f32 combine", "data": "synthetic",
-            "config": {"workload": f"{cfg.name} {args.qtype.upper()} (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
-                       "parallelism": "single GPU" if world == 1 else shard_description(lmrs_amd, model, world, transport),
-                       "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "prefill": prefill,
-        }
-        print(json.dumps(out), flush=True)
-    model.close()
+                    model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world)
+                    handles = [None] * world
+                    dist.all_gather_object(handles, model.p2p_handle())
+                    model.p2p_connect(handles)
+                except Exception as e:                      # noqa: BLE001 - any failure means: fall back, together
+                    print(f"[rank {rank}] peer-to-peer transport unavailable: {e}", file=sys.stderr)
+                    ok = 0
+                if all_ranks_ok(ok == 1):
+                    transport = "p2p"
+                else:
+                    if model is not None:
+                        model.close()
+                    model = None
+            if model is None:
+                uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
+                model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
+                transport = "rccl"
+        else:
+            model = lmrs_amd.Transformer(img, device=local_rank)
+
+        def timed_run(model):
+            # ---- warm-up: the W prompt tokens (token by token, as the reference feeds prompts), untimed
+            first = model.generate_greedy(prompt, 1)
+            device_sync(); barrier()
+            # ---- timed: exactly K decode steps at positions W .. W+K-1
+            t1 = time.perf_counter()
+            toks, dev_sec = model.generate_greedy(first, K, start_pos=W, timing=True)
+            device_sync(); barrier()
+            t2 = time.perf_counter()
+            return first, toks, dev_sec, t2 - t1
+
+        if transport == "p2p":
+            # a peer-to-peer exchange that times out mid-run (bounded wait, sticky error) must not cost the job its result: every rank
+            # reports, and if any of them failed all of them redo the run over RCCL
+            res = None
+            try:
+                res = timed_run(model)
+            except Exception as e:                          # noqa: BLE001
+                print(f"[rank {rank}] peer-to-peer run failed: {e}", file=sys.stderr)
+            if not all_ranks_ok(res is not None):
+                model.close()
+                uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
+                model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)
+                transport = "rccl (peer-to-peer run failed)"
+                res = timed_run(model)
+        else:
+            res = timed_run(model)
+        first, toks, dev_sec, wall = res
+        # the driver times few steps at the very first positions; the figure over the full 128-token generate of BASELINE.json's configs
+        # (positions W .. W+127: longer contexts, a run long enough to be immune to start-up noise) rides along when K differs
+        v128 = None
+        if not sharded and K != 128 and W + 128 <= 8192:
+            first128 = model.generate_greedy(prompt, 1)
+            device_sync()
+            t1 = time.perf_counter(); model.generate_greedy(first128, 128, start_pos=W); device_sync()
+            v128 = round(128 / (time.perf_counter() - t1), 1)
+            res2 = timed_run(model)                    # leave the context where the timed run left it (bench_step continues from there)
+            del res2
+        elapsed = max_over_ranks(dist, wall, ("cpu" if dist.get_backend() == "gloo" else "cuda") if dist is not None else None)
+        gen = np.concatenate([first, toks])[: K + 1]          # token ids produced after positions W-1 .. W+K-1
+        shard_steps = None
+        if sharded:
+            # per-kernel / per-exchange durations inside the sharded step (every rank takes part: the exchanges wait for the peers)
+            try:
+                shard_steps = model.bench_step(W + K, 8)
+            except Exception as e:                          # noqa: BLE001
+                print(f"[rank {rank}] bench_step: {e}", file=sys.stderr)
+            barrier()
+
+        out = None
+        if rank == 0:
+            tok_s = K / elapsed                      # one decode stream, whatever the number of GPUs
+            # whole-path bytes (SURVEY.md §8d) over the timed positions
+            path_bytes = sum(model.step_info(p)[1] for p in range(W, W + K))
+            n_launch = model.step_info(W)[0]
+            # ---- dominant kernel: per-shape live timing with HIP events
+            path = {"bytes_per_step": round(path_bytes / K), "us_per_step": round(elapsed / K * 1e6, 2),
+                    "achieved": round(path_bytes / elapsed / 1e9, 1), "frac": round(path_bytes / elapsed / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                    "kernel_launches_per_step": n_launch, "device_event_us_per_step": round(dev_sec / K * 1e6, 2)}
+            if sharded:
+                # SURVEY.md §8e: where a sharded step goes - streaming kernels, glue, exchanges, and what is left (launch gaps)
+                split = None
+                if shard_steps:
+                    iters = 8
+                    per = {k: {"us": round(us / n, 3), "launches_per_step": n // iters} for k, (us, _b, n) in shard_steps.items()}
+                    stream_us = sum(us for k, (us, _b, n) in shard_steps.items() if k not in ("exchange", "glue")) / iters
+                    glue_us = shard_steps.get("glue", (0.0, 0, 0))[0] / iters
+                    ex_us = shard_steps.get("exchange", (0.0, 0, 0))[0] / iters
+                    gemv_b = sum(_b for k, (us, _b, n) in shard_steps.items() if k in ("qkv", "wo", "w1w3", "w2", "classifier")) / iters
+                    gemv_us = sum(us for k, (us, _b, n) in shard_steps.items() if k in ("qkv", "wo", "w1w3", "w2", "classifier")) / iters
+                    split = {"stream_us": round(stream_us, 2), "glue_us": round(glue_us, 2),
+                             "exchange_us": round(ex_us, 2) if transport == "p2p" else None,
+                             "gap_us": round(elapsed / K * 1e6 - stream_us - glue_us - (ex_us if transport == "p2p" else 0.0), 2),
+                             "gemv_GBps_this_rank": round(gemv_b / gemv_us / 1e3, 1) if gemv_us else None, "kernels": per,
+                             "note": "rank 0's eager replay of the real step with an event pair per dispatch; a dispatch's duration includes its launch boundary; "
+                                     "exchange_us includes waiting for the slowest peer; with RCCL the collectives carry no events and sit in gap_us"}
+                # weight bytes the job streams per step beyond ONE copy of the model (replicated matrices are read by every GPU): `frac` prices
+                # the single-copy bytes against N x 8 TB/s, so it is a scaling figure, not a streaming efficiency, whenever this is not 0
+                pl = lmrs_amd.shard_plan(model.args, 0, world)
+                a_ = model.args; scb = (1.0 if args.qtype == "q8_0" else 0.5) + 4.0 / 128
+                att_f = a_.n_heads * a_.head_size; kv_f = a_.n_kv_heads * a_.head_size
+                one = a_.n_layers * (a_.dim * (att_f + 2 * kv_f) + att_f * a_.dim + 3 * a_.dim * a_.hidden_dim) * scb + a_.vocab_size * a_.dim * scb
+                per_gpu = a_.n_layers * (a_.dim * (pl["q_heads"][1] + 2 * pl["kv_heads"][1]) * a_.head_size + att_f * pl["dim_rows"][1]
+                                         + 2 * a_.dim * pl["hidden_pairs"][1] + a_.hidden_dim * pl["dim_rows"][1]) * scb + pl["vocab_rows"][1] * a_.dim * scb
+                redundant = int(round(world * per_gpu - one))
+                roofline = {"bound": "hbm", "kernel": "whole sharded step", "achieved": path["achieved"], "redundant_bytes_per_step": redundant,
+                            "bytes_streamed_per_gpu_per_step": int(round(per_gpu)),
+                            "peak": HBM_PEAK_GBPS * world, "unit": "GB/s", "frac": path["frac"], "traffic": None, "path": path,
+                            "transport": transport, "sharded_step_is_one_hipgraph": model.shard_uses_graph(), "step_split": split}
+            else:
+              # the real step, replayed eagerly from the live state with an event pair on every dispatch: each kernel's
+              # duration as it runs inside the step (real predecessor, real activations, positions W+K+1 ...)
+              iters = 8
+              res = model.bench_step(W + K, iters)
+              per, tot_us, tot_b, n_gemv, step_us = {}, 0.0, 0.0, 0, 0.0
+              for name, (us, b, n) in res.items():
+                per[name] = {"us": round(us / n, 3), "MB": round(b / n / 1e6, 3), "GBps": round(b / us / 1e3, 1), "launches_per_step": n // iters}
+                step_us += us / iters
+                if name not in ("attention", "argmax"):
+                  tot_us += us / iters; tot_b += b / iters; n_gemv += n // iters
+              achieved = tot_b / tot_us / 1e3            # GB/s
+              rp_us = rocprof_family_us(cfg.name, args.qtype)
+              roofline = {
+                "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel (fused dequant-GEMV, all shapes of one step), durations taken inside the real step",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "frac_vs_measured_copy": round(achieved / MEASURED_COPY_GBPS, 4),
+                # the same bytes over rocprofv3's average durations of the same kernels (committed summary of this build, else null): the
+                # profiler's per-dispatch intervals overlap at the launch boundaries and run a few percent above the event intervals
+                "frac_rocprof": round(tot_b / rp_us / 1e3 / HBM_PEAK_GBPS, 4) if rp_us else None,
+                "traffic": pmc_traffic(cfg.name, args.qtype),
+                "bytes_per_launch_avg": round(tot_b / n_gemv), "avg_launch_us": round(tot_us / n_gemv, 3), "launches_per_step": n_gemv,
+                "in_step": per, "sum_of_kernel_us_per_step": round(step_us, 2), "kernel_source_hash": kernel_source_hash(),
+                "path": path,
+              }
+            # ---- CPU baseline + parity gate
+            cpu = None; parity = None
+            cpu_steps = K if args.cpu_steps < 0 else args.cpu_steps
+            if cpu_steps > 0:
+                import oracle_lib as O
+                if args.cpu_threads > 0:
+                    os.environ["LMRS_REF_THREADS"] = str(args.cpu_threads)
+                elif "LMRS_REF_THREADS" not in os.environ:
+                    # the team the host can really run: affinity mask capped by the container's CPU quota (OpenMP sees only the former,
+                    # and 16 spinning threads on a 2-CPU quota are an order of magnitude slower than 2)
+                    budget = len(os.sched_getaffinity(0))
+                    try:
+                        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                        if quota != "max":
+                            budget = min(budget, max(1, int(quota) // int(period)))
+                    except (OSError, ValueError):
+                        pass
+                    os.environ["LMRS_REF_THREADS"] = str(min(16, budget))
+                orc = O.Oracle(img)
+                n_new = min(cpu_steps, K) + 1
+                ref, sec = orc.generate_greedy(prompt, n_new, timing=True)
+                steps_run = W + n_new - 1
+                cpu = {"value": round(steps_run / sec, 2), "unit": "tok/s", "cores": O.threads(), "kind": "port",
+                       "sample": f"same image and prompt: {W} prompt + {n_new - 1} greedy steps in {sec:.2f}s, OpenMP over rows/heads"}
+                parity = {"tokens_compared": int(n_new), "tokens_equal": bool((ref == gen[:n_new]).all())}
+            # ---- batched forward_layer (fill_kv_cache, SURVEY.md §8(f)1): the path's only dense contraction, int8 MFMA
+            prefill = None
+            if not sharded and args.qtype == "q8_0" and cfg.model_type != S.GEMMA:
+                n_pf = 256
+                emb = model.get_embeddings(S.prompt_tokens(cfg, n_pf, 4321))
+                best = 1e9
+                for _ in range(2):
+                    e = emb.copy()
+                    t_a = time.perf_counter(); model.fill_kv_cache(e, 0); best = min(best, time.perf_counter() - t_a)
+                att = cfg.n_heads * cfg.head_size; kvd = cfg.n_kv_heads * cfg.head_size
+                macs = n_pf * cfg.n_layers * (cfg.dim * (att + 2 * kvd) + att * cfg.dim + 3 * cfg.dim * cfg.hidden_dim)
+                prefill = {"tokens": n_pf, "ms": round(best * 1e3, 2), "tok_s": round(n_pf / best, 1), "achieved": round(2 * macs / best / 1e12, 1),
+                           "peak": 3944.0, "unit": "int8 TOP/s", "bound": "mfma", "frac": round(2 * macs / best / 1e12 / 3944.0, 4),
+                           "kernel": "lmrs::gemm_q8_kernel (v_mfma_i32_16x16x64_i8) + per-token rows, host<->device copies of the embeddings included"}
+            # ---- BASELINE configs[4]: the image path in the reference's call order (chat.rs:84-121) - CLIP tower over the global crop and
+            # one sub-image (2 crops x 577 tokens x 23 of 24 layers), projector, fill_kv_cache over the 4 + 313 + 3 embeddings
+            vision = None
+            if args.vision and not sharded and args.qtype == "q8_0":
+                from tools import synth_vision as V
+                def best_of(n, f):
+                    b, r = 1e9, None
+                    for _ in range(n):
+                        t_a = time.perf_counter(); r = f(); b = min(b, time.perf_counter() - t_a)
+                    return b, r
+                vcfg = V.VisionCfg(n_layers=24)
+                vt = lmrs_amd.VisionTransformer(V.build_vision_section(vcfg)); pv = V.pixel_values(vcfg, 2)
+                t_tower, feats = best_of(3, lambda: vt.forward(pv, 2))
+                pr = lmrs_amd.PHI3VProcessor(V.build_processor_section(4 * vcfg.dim, cfg.dim))
+                t_proj, img_emb = best_of(3, lambda: pr.forward(feats, 576 * vcfg.dim, 12, 1, 1))
+                pre = model.get_embeddings(np.array([1, 32010, 29871, 13], np.uint32)); post = model.get_embeddings(np.array([1, 29871, 13], np.uint32))
+                prefix = np.concatenate([pre.reshape(-1), img_emb.reshape(-1), post.reshape(-1)]).astype(np.float32)
+                n_emb = prefix.size // cfg.dim
+                t_fill, _ = best_of(2, lambda: model.fill_kv_cache(prefix.copy(), 0))
+                ntok = 2 * 577
+                tower_macs = ntok * (vcfg.n_layers - 1) * (4 * vcfg.dim * vcfg.dim + 2 * vcfg.dim * vcfg.hidden_dim)
+                proj_macs = img_emb.shape[0] * (4 * vcfg.dim * cfg.dim + cfg.dim * cfg.dim)
+                att = cfg.n_heads * cfg.head_size; kvd = cfg.n_kv_heads * cfg.head_size
+                fill_macs = n_emb * cfg.n_layers * (cfg.dim * (att + 2 * kvd) + att * cfg.dim + 3 * cfg.dim * cfg.hidden_dim)
+                tot_t = t_tower + t_proj + t_fill
+                # parity of the image features against the CPU restatement on a 3-layer tower (the full depth is tests/test_gpu_parity.py::
+                # test_vision_tower_at_full_depth; here the CPU leg must stay short) and of the projector on the full-depth features
+                import oracle_lib as O
+                v3 = V.VisionCfg(n_layers=3); sec3 = V.build_vision_section(v3)
+                f3 = lmrs_amd.VisionTransformer(sec3).forward(pv, 2); o3 = O.VisionOracle(sec3).forward(pv, 2)
+                po = O.ProcessorOracle(V.build_processor_section(4 * vcfg.dim, cfg.dim)).forward(feats, 576 * vcfg.dim, 12, 1, 1)
+                vision = {"tower_ms": round(t_tower * 1e3, 2), "tower_shape": "2 crops x 577 tokens x 23 layers (CLIP ViT-L/14-336)", "projector_ms": round(t_proj * 1e3, 2),
+                          "image_embeddings": int(img_emb.shape[0]), "fill_kv_cache_embeddings": int(n_emb), "fill_kv_cache_ms": round(t_fill * 1e3, 2),
+                          "tower_TOPs": round(2 * tower_macs / t_tower / 1e12, 1), "fill_TOPs": round(2 * fill_macs / t_fill / 1e12, 1),
+                          "achieved": round(2 * (tower_macs + proj_macs + fill_macs) / tot_t / 1e12, 1), "peak": 3944.0, "unit": "int8 TOP/s", "bound": "mfma",
+                          "frac": round(2 * (tower_macs + proj_macs + fill_macs) / tot_t / 1e12 / 3944.0, 4),
+                          "note": "int8 MACs of the projections only (attention and norms are f32 vector work); host<->device copies of pixels / features / embeddings included",
+                          "parity": {"tower_3_layers_bit_equal": bool((f3.view(np.uint32) == o3.reshape(f3.shape).view(np.uint32)).all()),
+                                     "projector_bit_equal": bool((img_emb.reshape(-1).view(np.uint32) == po.reshape(-1).view(np.uint32)).all())}}
+            out = {
+                "metric": "decode tok/s + %HBM-roofline, Llama-3.2-1B Q8_0 @1/2/4/8 MI355X vs CPU ref",
+                "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": round(elapsed / K * 1e3, 5), "value_128_steps": v128 if K != 128 else round(tok_s, 1), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+                "vs_baseline": None, "dtype": "int8xint8->int32, f32 combine" if args.qtype == "q8_0" else "int4xint4->int32, f32 combine", "data": "synthetic",
+                "config": {"workload": f"{cfg.name} {args.qtype.upper()} (gs=128) greedy decode, {W}-token synthetic prompt then {K} tokens, batch 1",
+                           "parallelism": "single GPU" if world == 1 else shard_description(lmrs_amd, model, world, transport),
+                           "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
+                "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "prefill": prefill, "vision": vision,
+            }
+            print(json.dumps(out), flush=True)
+        model.close()
+        return out
+
+    out = run_once()
+    # LMRS_BENCH_BOTH_PLANS=1 (N > 1): a second line for the configuration north_star names - every weight matrix row-split ("tp"),
+    # slices exchanged by RCCL all-gathers over xGMI - next to the library's own choice above (for the small models: "cls" over the
+    # peer-to-peer transport), so that one multi-GPU run yields both.
+    if os.environ.get("LMRS_BENCH_BOTH_PLANS") == "1" and dist is not None:
+        barrier()
+        run_once(plan="tp", transport_override=None if os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1" else "rccl")   # (RCCL refuses two ranks on one device)
     if dist is not None:
         dist.destroy_process_group()
     return out

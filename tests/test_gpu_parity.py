@@ -539,6 +539,29 @@ def test_row_sharding_is_bit_identical(L, monkeypatch, cfg, q, world, mode):
     grp.close()
 
 
+def test_row_sharding_full_size_3b(L, monkeypatch):
+    """BASELINE.json configs[3] in its sharded form at FULL size: Llama-3.2-3B Q8_0 (28 layers, 24 query / 8 kv heads of 128, 128 256-row
+    vocabulary), every weight matrix row-split over 8 shards (plan `tp`: 3 query heads + 1 kv head, 1024 gate/up pairs and 16 032
+    classifier rows per shard; quantised int8 payloads), the 8 shards run in lock step on one device.  4 prompt + 8 greedy steps:
+    logits bit-equal to the CPU path at every step - the static / generic kernel choice for the shard shapes and the 16 032-row
+    classifier shard included."""
+    monkeypatch.setenv("LMRS_SHARD_PLAN", "tp")
+    cfg = "llama-3.2-3b"
+    img = S.build_image(cfg, S.Q8_0, seed=2024)
+    grp = L.ShardGroup(img, 8)
+    orc = O.Oracle(img)
+    prompt = S.prompt_tokens(cfg, 4, 2024)
+    tok = None
+    for pos in range(12):
+        t = int(prompt[pos]) if pos < len(prompt) else tok
+        lg, nxt = grp.forward(t, pos)
+        lo = orc.forward(t, pos)
+        assert_bit_equal(lg, lo, f"3B tp8 logits at pos {pos}")
+        tok = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+        assert nxt == tok
+    grp.close()
+
+
 @pytest.mark.parametrize("i", range(8))
 def test_row_sharding_on_random_geometries(L, monkeypatch, i):
     """Two logical shards of geometries nothing was written against (slices below one quantisation group fall back to f32 payloads;

@@ -2,9 +2,9 @@
 # Regenerates the round's measurement artefacts on a GPU box (run from the repo root through gpurun); everything lands in
 # gpurun_out/art/ and is copied into profiles/ by hand afterwards.  PMC counters are collected in their own rocprofv3 runs
 # (--kernel-trace only, one counter per pass), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-#   usage: bash tools/make_profiles.sh <tag>            (e.g. r2)
+#   usage: bash tools/make_profiles.sh <tag>            (e.g. r3)
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/art; rm -rf $OUT; mkdir -p $OUT
@@ -22,6 +22,9 @@ pmc gemma-2-2b q4_0 $OUT/${TAG}_traffic_gemma2b_q4.json
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --cpu-steps 0 > $OUT/stats.log 2>&1
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv; rm -rf $OUT/stats
+python tools/rocprof_summary.py $OUT/${TAG}_kernel_stats.csv $OUT/${TAG}_rocprof_llama1b_q8.json llama-3.2-1b q8_0 && cp $OUT/${TAG}_rocprof_llama1b_q8.json profiles/   # bench.py reads it (frac_rocprof)
+timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err                      # again: now with frac_rocprof and traffic of this build
+timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2>> $OUT/bench.err   # the driver's invocation
 timeout 300 python bench.py --model gemma-2-2b --qtype q4_0 --steps 64 > $OUT/${TAG}_bench_gemma2b_q4.json 2>> $OUT/bench.err
 timeout 400 python bench.py --model llama-3.2-3b --steps 64 > $OUT/${TAG}_bench_llama3b.json 2>> $OUT/bench.err
 timeout 400 python bench.py --model phi-3.5 --steps 64 > $OUT/${TAG}_bench_phi35.json 2>> $OUT/bench.err
@@ -32,6 +35,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vis -- 
 cp $(ls $OUT/vis/*/*kernel_stats.csv | head -1) $OUT/${TAG}_vision_kernel_stats.csv; rm -rf $OUT/vis
 LMRS_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29581 bench.py --gpus 2 --steps 64 --warmup 16 --cpu-steps 8 2> $OUT/tp2.err | grep '^{' > $OUT/${TAG}_bench_tp2_two_ranks_one_device.json
 LMRS_SHARD_PLAN=tp LMRS_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29585 bench.py --gpus 2 --steps 64 --warmup 16 --cpu-steps 8 2>> $OUT/tp2.err | grep '^{' > $OUT/${TAG}_bench_tp2_plan_tp_two_ranks_one_device.json
+timeout 400 python bench.py --model phi-3.5 --steps 32 --vision > $OUT/${TAG}_bench_phi35_vision.json 2>> $OUT/bench.err
 for f in $OUT/${TAG}_bench*.json; do python - "$f" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]

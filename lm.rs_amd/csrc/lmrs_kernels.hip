@@ -1211,13 +1211,23 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
             const unsigned long long* gq = tg.gran + h * HS + tid;
             const unsigned long long* gk = tg.gran + tg.att_dim + kvh * HS + tid;
             const unsigned long long* gv = tg.gran + tg.att_dim + tg.kv_dim + kvh * HS + tid;
-            unsigned long long x0, x1, x2;
+            unsigned long long x0, x1, x2, y0, y1, y2;
+            auto fresh = [&](unsigned long long p0, unsigned long long p1, unsigned long long p2) __attribute__((always_inline)) {
+                return __all((unsigned)(p0 >> 32) == tg.tag && (unsigned)(p1 >> 32) == tg.tag && (unsigned)(p2 >> 32) == tg.tag) != 0;
+            };
+            // two sweeps in flight (a sweep's latency, not up to twice it, after the store)
+            x0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x1 = __hip_atomic_load(gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x2 = __hip_atomic_load(gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (unsigned spins = 0;; ++spins) {
+                y0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                y1 = __hip_atomic_load(gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                y2 = __hip_atomic_load(gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (fresh(x0, x1, x2)) break;
                 x0 = __hip_atomic_load(gq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x1 = __hip_atomic_load(gk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x2 = __hip_atomic_load(gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = (unsigned)(x0 >> 32) == tg.tag && (unsigned)(x1 >> 32) == tg.tag && (unsigned)(x2 >> 32) == tg.tag;
-                if (__all(ok)) break;
+                if (fresh(y0, y1, y2)) { x0 = y0; x1 = y1; x2 = y2; break; }
                 if (spins > kTagSpinMax || (spins & 1023) == 1023) {     // bounded: report and finish with garbage instead of hanging
                     const int e = __hip_atomic_load(tg.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (e != 0 || spins > kTagSpinMax) {
@@ -1225,7 +1235,6 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(1);
             }
             q[tid] = __uint_as_float((unsigned)x0); kn[tid] = __uint_as_float((unsigned)x1); vn[tid] = __uint_as_float((unsigned)x2);
         }
@@ -1272,7 +1281,10 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
             vn[j + half] = ld_f32<true>(vbase + (size_t)pos * kv_dim + j + half);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the key stores have reached the cache hierarchy (and the batches loaded above have landed)
+    // the key stores must have reached the cache hierarchy before a lane loads the key of `pos` from memory: further batches of the key
+    // (heads wider than one batch) or further passes (T > 256).  Otherwise that lane's whole key is patched from LDS below and the wait -
+    // a memory round trip on the critical path of every layer - is skipped (merged launch, short contexts).
+    if (!TAG || HS / 4 > KG || T > kBlock) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     ATT_STAMP(2);
     if (!ROT && tc0 == pos) {                          // batch 0 was loaded before the new key existed: patch it from LDS
@@ -1316,13 +1328,17 @@ __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos
         const float e = expf_glibc_t(t < T ? att[t] - mx : 0.0f, etab);
         if (t < T) att[t] = e;
     }
-    if (tid < 32) att[T + tid] = 0.0f;                       // +0.0 padding for the batched serial sum
+    if (tid < 64) att[T + tid] = 0.0f;                       // +0.0 padding for the serial sum (exact: the running sum of exponentials is >= +0)
     lds_barrier();
-    if (tid == 0) {
-        // serial sum (functional.rs:134); the ragged tail is padded with +0.0 (att[T .. T+31] above; exact: the running
-        // sum of exponentials is >= +0), so there is no one-LDS-read-per-add tail loop
-        const float sum = serial_sum16<1>(0.0f, att, T);
-        red[4] = sum;
+    if (tid < 64) {
+        // serial sum (functional.rs:134) in wave 0: 64 exponentials per register, added lane by lane through the add's own DPP operand
+        // (wave_serial_sum: one dependent add per term and nothing else - the LDS-fed chain cost ~7 cycles per term)
+        float sum = 0.0f;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int left = T - t0;
+            sum = wave_serial_sum(sum, att[t0 + tid], left >= 64 ? 4 : (left + 15) >> 4);
+        }
+        if (tid == 0) red[4] = sum;
     }
     lds_barrier();
     const float sum = red[4];

@@ -157,6 +157,9 @@ int lmrs_op_expf(int device, float* y, const float* x, size_t n);
 /* y = (float)tanh(c * (double)x): f64::tanh as the reference calls it for Gemma's soft-caps (transformer.rs:520-522, 377-379; c = 1) and
  * the tanh-GELU (transformer.rs:614; c = 0.7978845608028654) - the device's f64 tanh, for comparison with the host libm (oracle/tanh_check.c). */
 int lmrs_op_tanh_cast(int device, float* y, const float* x, size_t n, double c);
+/* Sampler::sample (sampler.rs:109-129) for temperature != 0 and sample_mult, on the device, on caller-supplied logits: they are scaled and
+ * softmax-ed IN PLACE (as the reference does to the slice) and *token = the draw for the random number rnd.  Unit parity for lmrs_forward_sample. */
+int lmrs_op_sample_mult(int device, float* logits, size_t n, float temperature, float rnd, uint32_t* token);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------
  * Runs, `iters` times, the dequant-GEMV launches of ONE decode step in step order (per layer: qkv, wo,
@@ -254,6 +257,13 @@ typedef struct lmrs_sampler lmrs_sampler;
 int lmrs_sampler_create(uint32_t vocab_size, float temperature, float top_p, uint64_t seed, lmrs_sampler** out);
 void lmrs_sampler_destroy(lmrs_sampler* s);
 int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
+int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd);   /* rnd = random_f32(seed), the same on every call (:119) */
+/* Transformer::forward (src/transformer.rs:316) followed by Sampler::sample (src/sampler.rs:109-129) with the logits staying in HBM:
+ * temperature 0 -> the argmax fused into the decode step; temperature != 0 with top_p outside (0, 1) -> temperature scaling, softmax in
+ * place and sample_mult ON THE DEVICE (sample_*_kernel: the reference's sequential sums run lane by lane in one wave); top_p inside (0, 1)
+ * (sample_topp: a stable sort of the sampler's persistent candidate vector, :67-106) -> lmrs_forward + lmrs_sampler_sample on the host.
+ * Same token as lmrs_forward + lmrs_sampler_sample in every case.  One-GPU contexts. */
+int lmrs_forward_sample(lmrs_ctx* ctx, uint32_t token, uint32_t pos, lmrs_sampler* sampler, uint32_t* next);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
@@ -118,6 +118,9 @@ def lib():
         L.lmrs_sampler_create.argtypes = [u32, C.c_float, C.c_float, C.c_uint64, C.POINTER(vp)]
         L.lmrs_sampler_destroy.argtypes = [vp]; L.lmrs_sampler_destroy.restype = None
         L.lmrs_sampler_sample.argtypes = [vp, vp, C.POINTER(u32)]
+        L.lmrs_sampler_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.lmrs_forward_sample.argtypes = [vp, u32, u32, vp, C.POINTER(u32)]
+        L.lmrs_op_sample_mult.argtypes = [C.c_int, vp, sz, C.c_float, C.c_float, C.POINTER(u32)]
         L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
         L.lmrs_p2p_handle.argtypes = [vp, vp]
         L.lmrs_p2p_connect.argtypes = [vp, vp]
@@ -175,6 +178,12 @@ class Transformer:
     def forward_argmax(self, token: int, pos: int) -> int:
         n = C.c_uint32()
         _chk(lib().lmrs_forward_argmax(self._h, token, pos, C.byref(n)))
+        return n.value
+
+    def forward_sample(self, token: int, pos: int, sampler: "Sampler") -> int:
+        """forward + Sampler::sample with the logits staying on the device (argmax / temperature + sample_mult; top-p goes through the host)"""
+        n = C.c_uint32()
+        _chk(lib().lmrs_forward_sample(self._h, token, pos, sampler._h, C.byref(n)))
         return n.value
 
     def get_embeddings(self, tokens) -> np.ndarray:
@@ -343,6 +352,14 @@ def expf(x, device=0):
     return y
 
 
+def sample_mult(logits, temperature: float, rnd: float, device=0):
+    """Sampler::sample (temperature != 0, sample_mult) on the device -> (token, the probabilities the logits were turned into)"""
+    lg = np.ascontiguousarray(logits, np.float32).copy()
+    tok = C.c_uint32()
+    _chk(lib().lmrs_op_sample_mult(device, _p(lg), lg.size, C.c_float(temperature), C.c_float(rnd), C.byref(tok)))
+    return tok.value, lg
+
+
 def tanh_cast(x, c=1.0, device=0):
     """(float)tanh(c * (double)x) as the kernels evaluate it (Gemma soft-caps: c = 1; tanh-GELU: c = 0.7978845608028654)"""
     x = np.ascontiguousarray(x, np.float32)
@@ -472,6 +489,12 @@ class Sampler:
         nxt = C.c_uint32()
         _chk(lib().lmrs_sampler_sample(self._h, _p(logits), C.byref(nxt)))
         return nxt.value
+
+    def info(self):
+        """(vocab_size, temperature, top_p, the random number every call draws: random_f32(seed), sampler.rs:119)"""
+        v = C.c_uint32(); t = C.c_float(); p = C.c_float(); r = C.c_float()
+        _chk(lib().lmrs_sampler_info(self._h, C.byref(v), C.byref(t), C.byref(p), C.byref(r)))
+        return v.value, t.value, p.value, r.value
 
     def close(self):
         if getattr(self, "_h", None):

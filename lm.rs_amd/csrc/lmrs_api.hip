@@ -1108,6 +1108,30 @@ extern "C" int lmrs_forward_argmax(lmrs_ctx* c, uint32_t token, uint32_t pos, ui
     return 0;
 }
 
+struct lmrs_sampler;
+extern "C" int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd);
+extern "C" int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
+extern "C" int lmrs_forward_sample(lmrs_ctx* c, uint32_t token, uint32_t pos, lmrs_sampler* sampler, uint32_t* next) {
+    if (!c || !sampler || !next) return fail("NULL argument");
+    uint32_t vs = 0; float temp = 0, top_p = 0, rnd = 0;
+    if (lmrs_sampler_info(sampler, &vs, &temp, &top_p, &rnd)) return -1;
+    if (vs != c->args.vocab_size) return fail("the sampler was made for another vocabulary size");
+    if (temp == 0.0f) return lmrs_forward_argmax(c, token, pos, next);                    // sample_argmax: fused into the step
+    if ((top_p > 0.0f && top_p < 1.0f) || c->world > 1 || c->comm) {                       // sample_topp / sharded logits: the host sampler
+        float* lg = nullptr;
+        if (lmrs_forward(c, token, pos, &lg)) return -1;
+        return lmrs_sampler_sample(sampler, lg, next);
+    }
+    if (step_once(c, token, pos)) return -1;
+    SampleArgs sa{c->logits, (int)c->args.vocab_size, temp, rnd, c->part_val, c->part_val + kSampleGrid + 1, c->tokens + c->args.seq_len + 4};   // (scratch: the argmax partials; a spare token slot)
+    HIP_OK(launch_sample_mult(sa, c->stream));
+    HIP_OK(hipMemcpyAsync(c->h_tok + 1, sa.out_token, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (check_err(c)) return -1;
+    *next = c->h_tok[1];
+    return 0;
+}
+
 extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, size_t n, float* out) {
     lmrs_ctx* c = const_cast<lmrs_ctx*>(cc);
     if (!c || !tokens || !out) return fail("NULL argument");
@@ -1633,6 +1657,19 @@ extern "C" int lmrs_op_classifier_argmax(int device, const float* x, const float
     if (tk[1] != tk2[1]) return fail("classifier argmax: the folded form answered " + std::to_string(tk[1]) + ", the two-launch form " + std::to_string(tk2[1]));
     *token = tk[1];                                     // tokens[pos + 1] with pos = 0, prompt_end = 0
     if (logits) HIP_OK(hipMemcpy(logits, dl, o * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lmrs_op_sample_mult(int device, float* logits, size_t n, float temperature, float rnd, uint32_t* token) {
+    if (op_begin(device)) return -1;
+    if (!logits || !token || n == 0 || temperature == 0.0f) return fail("bad argument (temperature 0 is sample_argmax: lmrs_op_classifier_argmax)");
+    Scratch S; void *dl = S.get(n * 4), *dp = S.get((kSampleGrid + 8) * 4), *dt = S.get(16);
+    if (!dt) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dl, logits, n * 4, hipMemcpyHostToDevice));
+    SampleArgs sa{static_cast<float*>(dl), (int)n, temperature, rnd, static_cast<float*>(dp), static_cast<float*>(dp) + kSampleGrid + 1, static_cast<uint32_t*>(dt)};
+    HIP_OK(launch_sample_mult(sa, nullptr));
+    HIP_OK(hipMemcpy(token, dt, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(logits, dl, n * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -120,6 +120,12 @@ hipError_t launch_addnorm(float* x, const float* delta, const float* w, int n, f
 hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s);
 hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint32_t* tokens, int n_tok, int dim, float* out, hipStream_t st);
 
+// ---- Sampler::sample on the device (sampler.rs:109-129 for temperature != 0 and top_p outside (0, 1): temperature scaling, softmax
+// in place, sample_mult).  scratch: n_part floats of per-workgroup maxima + 1 float (the sum); *out_token receives the draw.
+struct SampleArgs { float* logits; int n; float temperature; float rnd; float* part; float* sum; uint32_t* out_token; };
+constexpr int kSampleGrid = 256;
+hipError_t launch_sample_mult(const SampleArgs& a, hipStream_t s);
+
 // thin kernels over the same device functions, for the lmrs_op_* unit-parity entry points
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st);
 hipError_t launch_rmsnorm(const float* x, const float* w, float* o, int n, float eps, int add_unit, hipStream_t st);

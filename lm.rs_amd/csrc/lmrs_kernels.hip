@@ -1967,6 +1967,100 @@ hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sampler::sample on the device (sampler.rs:109-129, the temperature != 0 branch with sample_mult :43-55): the logits never leave HBM.
+//   1. logits[i] /= temperature (:115), per-workgroup maxima                                   [grid]
+//   2. logits[i] = exp(logits[i] - max) (functional.rs:126-133: max starts at x[0], strict >)   [grid]
+//   3. sum: the reference's ONE sequential chain over all n exponentials (functional.rs:134) - a single wave, 64 terms per
+//      register, added lane by lane through the add's DPP operand (wave_serial_sum): one dependent add per term, 0.2 ms for 128 256
+//   4. logits[i] /= sum (:137-139)                                                               [grid]
+//   5. sample_mult: the running cdf in the same way, block of 64 by block of 64, until it passes the random number; the crossing is
+//      then located term by term inside that block (the cdf never decreases: probabilities are >= 0)
+// Bit-identical to the host sampler (lmrs_text.cpp) by construction: same operations, same order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void sample_scale_max_kernel(const SampleArgs a) {
+    __shared__ float red[kBlock / 64];
+    float m = __uint_as_float(0xff800000u);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) {
+        const float v = a.logits[i] / a.temperature;
+        a.logits[i] = v;
+        if (i == 0) a.part[gridDim.x] = v;                        // x[0]: where the reference's max scan starts (step 2 needs it after block 0 has overwritten it)
+        m = fmaxf(m, v);                                          // (NaNs are skipped here; a NaN at index 0 is put back in step 2)
+    }
+    m = wave64_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) a.part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(kBlock) void sample_exp_kernel(const SampleArgs a, int n_part) {
+    __shared__ float red[kBlock / 64];
+    float m = __uint_as_float(0xff800000u);
+    for (int i = threadIdx.x; i < n_part; i += kBlock) m = fmaxf(m, a.part[i]);
+    m = wave64_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float x0 = a.part[n_part];
+    if (!(x0 == x0)) mx = x0;                                    // max_val starts at x[0] and only moves on a strict `>`: a NaN there stays
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) a.logits[i] = expf_glibc(a.logits[i] - mx);
+}
+// 64 terms per register, 8 registers in flight; terms past n are +0.0 (exact no-ops on a running sum that starts at +0.0)
+__device__ __forceinline__ float sample_block(const float* x, int i0, int n, int lane) { const int i = i0 + lane; return i < n ? x[i] : 0.0f; }
+__global__ __launch_bounds__(64) void sample_sum_kernel(const SampleArgs a) {
+    const int lane = threadIdx.x;
+    float sum = 0.0f;
+    for (int i0 = 0; i0 < a.n; i0 += 512) {
+        float e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) e[u] = sample_block(a.logits, i0 + 64 * u, a.n, lane);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 64 * u < a.n) { const int left = a.n - (i0 + 64 * u); sum = wave_serial_sum(sum, e[u], left >= 64 ? 4 : (left + 15) >> 4); }   // wave-uniform
+    }
+    if (lane == 0) *a.sum = sum;
+}
+__global__ __launch_bounds__(kBlock) void sample_div_kernel(const SampleArgs a) {
+    const float sum = *a.sum;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) a.logits[i] = a.logits[i] / sum;
+}
+__global__ __launch_bounds__(64) void sample_pick_kernel(const SampleArgs a) {
+    const int lane = threadIdx.x;
+    float cdf = 0.0f;
+    uint32_t pick = (uint32_t)(a.n - 1);                         // sampler.rs:54: rounding left the cdf below the random number
+    bool found = false;
+    for (int i0 = 0; i0 < a.n && !found; i0 += 512) {
+        float p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = sample_block(a.logits, i0 + 64 * u, a.n, lane);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (!found && i0 + 64 * u < a.n) {                   // wave-uniform
+                const int left = a.n - (i0 + 64 * u);
+                const float before = cdf;
+                cdf = wave_serial_sum(cdf, p[u], left >= 64 ? 4 : (left + 15) >> 4);
+                if (a.rnd < cdf) {                               // the crossing is inside this block: the same adds once more, term by term
+                    float c = before;
+                    for (int l = 0; l < 64 && i0 + 64 * u + l < a.n; ++l) {
+                        c = c + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p[u]), l));
+                        if (a.rnd < c) { pick = (uint32_t)(i0 + 64 * u + l); break; }
+                    }
+                    found = true;
+                }
+            }
+        }
+    }
+    if (lane == 0) *a.out_token = pick;
+}
+hipError_t launch_sample_mult(const SampleArgs& a, hipStream_t s) {
+    if (a.n <= 0 || !a.logits || !a.part || !a.sum || !a.out_token) return hipErrorInvalidValue;
+    LMRS_LAUNCH_GRID(sample_scale_max_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
+    LMRS_LAUNCH_GRID(sample_exp_kernel, dim3(kSampleGrid), kBlock, 0, s, a, (int)kSampleGrid);
+    LMRS_LAUNCH_GRID(sample_sum_kernel, dim3(1), 64, 0, s, a);
+    LMRS_LAUNCH_GRID(sample_div_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
+    LMRS_LAUNCH_GRID(sample_pick_kernel, dim3(1), 64, 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Thin kernels for the lmrs_op_* entry points: the same device functions as the fused path.
 // ------------------------------------------------------------------------------------------------
 template <bool Q4>

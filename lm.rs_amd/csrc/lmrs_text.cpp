@@ -244,6 +244,17 @@ extern "C" int lmrs_sampler_create(uint32_t vocab_size, float temperature, float
 }
 extern "C" void lmrs_sampler_destroy(lmrs_sampler* s) { delete s; }
 
+// the sampler's parameters and the random number every call of it draws (random_f32(seed): the seed never advances, sampler.rs:119) -
+// what lmrs_forward_sample needs to run Sampler::sample on the device
+extern "C" int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd) {
+    if (!s) return text_fail("NULL argument");
+    if (vocab_size) *vocab_size = s->vocab_size;
+    if (temperature) *temperature = s->temperature;
+    if (top_p) *top_p = s->top_p;
+    if (rnd) *rnd = random_f32(s->seed);
+    return 0;
+}
+
 // Sampler::sample (sampler.rs:109-129).  logits (vocab_size floats) are scaled and softmax-ed IN PLACE when temperature != 0, as
 // the reference does to the slice `forward` returned.  The random number is random_f32(self.seed) on every call: the seed is
 // never advanced (:119), so one Sampler draws the same number each time - reproduced.

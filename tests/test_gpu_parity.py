@@ -46,6 +46,46 @@ def test_expf_matches_host_libm(L):
     assert_bit_equal(dev[1 << 20: (1 << 20) + (1 << 16)], np.array([O.expf(float(v)) for v in mid], np.float32), "expf wide range")
 
 
+@pytest.mark.parametrize("n,temperature", [(64, 1.0), (1000, 0.7), (4102, 1.3), (128256, 0.8), (32064, 2.0)])
+def test_sampler_on_the_device(L, n, temperature):
+    """Sampler::sample (sampler.rs:109-129; temperature != 0, sample_mult) on the device against the host sampler (lmrs_text.cpp, itself
+    checked against the second transcription in tests/text_ref.py): the probabilities the logits are turned into bit for bit - the
+    sequential softmax sum over the whole vocabulary runs lane by lane in one wave - and the same draw for random numbers across the
+    range, the first / last term and block-of-64 boundaries of the running cdf included."""
+    rng = np.random.default_rng(n)
+    logits = (rng.standard_normal(n) * 3).astype(np.float32)
+    host = L.Sampler(n, temperature, 1.0, 1)                      # top_p = 1: sample_mult
+    _, _, _, rnd0 = host.info()
+    want_probs = logits.copy(); want_tok = host.sample(want_probs)
+    tok, probs = L.sample_mult(logits, temperature, rnd0)
+    assert_bit_equal(probs, want_probs, f"softmax of {n} logits at temperature {temperature}")
+    assert tok == want_tok
+    # the draw for other random numbers: sample_mult restated on the (bit-equal) probabilities - numpy's f32 cumsum is the same
+    # sequential chain of f32 adds
+    cdf = np.cumsum(want_probs, dtype=np.float32)
+    def draw(r):
+        hit = np.flatnonzero(np.float32(r) < cdf)
+        return int(hit[0]) if hit.size else n - 1
+    for r in [0.0, 1e-9, 0.25, 0.5, 0.9, 0.999, 0.9999999, 1.0, float(cdf[min(n - 1, 63)]), float(cdf[min(n - 1, 64)]), float(cdf[min(n - 1, 511)]), float(cdf[n // 2])]:
+        t2, _ = L.sample_mult(logits, temperature, r)
+        assert t2 == draw(r), f"n={n} r={r}: device {t2}, host {draw(r)}"
+
+
+def test_forward_sample_matches_forward_plus_host_sampler(L):
+    """lmrs_forward_sample (logits stay in HBM) against lmrs_forward + lmrs_sampler_sample: greedy, temperature sampling, top-p."""
+    img = S.build_image("mini-llama", S.Q8_0, seed=77)
+    prompt = S.prompt_tokens("mini-llama", 4, 77)
+    for temperature, top_p in [(0.0, 0.9), (0.8, 1.0), (1.5, 0.0), (0.7, 0.9)]:
+        a = L.Transformer(img); b = L.Transformer(img)
+        sa = L.Sampler(a.args.vocab_size, temperature, top_p, 12345); sb = L.Sampler(b.args.vocab_size, temperature, top_p, 12345)
+        ta = tb = None
+        for pos in range(12):
+            t = int(prompt[pos]) if pos < len(prompt) else ta
+            ta = a.forward_sample(t, pos, sa)
+            tb = sb.sample(b.forward(t, pos))
+            assert ta == tb, f"temperature {temperature}, top_p {top_p}, pos {pos}: device {ta}, host {tb}"
+
+
 @pytest.mark.parametrize("c", [1.0, 0.7978845608028654])
 def test_tanh_matches_host_libm(L, c):
     """f64::tanh (Gemma's score / logit soft-caps, c = 1; the tanh-GELU, c = 0.79788...) is the one transcendental the device does

@@ -52,15 +52,18 @@ enum { LMRS_GEMMA = 0, LMRS_LLAMA = 1, LMRS_PHI = 2 };
  * KV cache and activation buffers there.  *bytes_consumed = offset of the first byte
  * after the text model (what the reference returns as the second tuple element).
  * The host image is not referenced after return.  Q8_0, Q4_0 (group size 128) and unquantised (q_type None, f32: the reference's
- * `matmul`, functional.rs:142-171) files of the Llama / Gemma-2 / Phi families; f32 files on one GPU only. */
+ * `matmul`, functional.rs:142-171) files of the Llama / Gemma-2 / Phi families; f32 files on one GPU only.  Geometry limits (all files the
+ * reference's exporter writes for its model families meet them): dim, n_heads * head_size and hidden_dim multiples of 128 - also for f32
+ * files, where the reference itself only needs multiples of 8 -, head_size 64 / 96 / 128 / 256, group_size 128. */
 int lmrs_create(const uint8_t* file, size_t len, int device, lmrs_ctx** out, size_t* bytes_consumed);
 
 /* Row-sharded variant (no reference counterpart - the reference is one process on one host; replaces the same
  * Transformer::new, transformer.rs:134): this process is shard `rank` of `world`
  * (one process per GPU).  `nccl_unique_id` points at the 128-byte ncclUniqueId created
  * by rank 0 and distributed by the host (e.g. torch.distributed broadcast); it may be
- * NULL when world == 1 - and with world > 1 it selects the peer-to-peer transport (lmrs_p2p_handle / lmrs_p2p_connect below).
- * Results are bit-identical to world == 1. */
+ * NULL when world == 1.  NOTE: with world > 1 a NULL id does NOT fail - it selects the peer-to-peer transport: the context is created
+ * unconnected and every step fails with "peers not connected" until lmrs_p2p_connect has run (lmrs_p2p_handle / lmrs_p2p_connect below;
+ * at most 8 shards: the GPUs of one node).  Results are bit-identical to world == 1. */
 int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world,
                         const void* nccl_unique_id, lmrs_ctx** out, size_t* bytes_consumed);
 

@@ -78,7 +78,7 @@ def pmc_traffic(model, qtype):
             doc = json.load(open(os.path.join(pdir, f)))
             if (doc.get("model"), doc.get("qtype"), doc.get("kernel_source_hash")) != want:
                 continue
-            k = {n: v for n, v in doc["kernels"].items() if "gemv" in n}
+            k = {n: v for n, v in doc["kernels"].items() if "gemv" in n or "qkv_attn" in n}     # the dequant-GEMV family (the qkv launch carries the attention workgroups)
             n = sum(v["launches"] for v in k.values())
             return round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in k.values()) / n) if n else None
         except (OSError, ValueError, KeyError):
@@ -335,7 +335,7 @@ def main():
               achieved = tot_b / tot_us / 1e3            # GB/s
               rp_us = rocprof_family_us(cfg.name, args.qtype)
               roofline = {
-                "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel (fused dequant-GEMV, all shapes of one step), durations taken inside the real step",
+                "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel / qkv_attn_kernel (fused dequant-GEMV, all shapes of one step; the qkv launch includes the attention workgroups merged into it, the classifier the folded argmax), durations taken inside the real step",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "frac_vs_measured_copy": round(achieved / MEASURED_COPY_GBPS, 4),
                 # the same bytes over rocprofv3's average durations of the same kernels (committed summary of this build, else null): the

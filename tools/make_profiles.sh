@@ -2,15 +2,23 @@
 # Regenerates the round's measurement artefacts on a GPU box (run from the repo root through gpurun); everything lands in
 # gpurun_out/art/ and is copied into profiles/ by hand afterwards.  PMC counters are collected in their own rocprofv3 runs
 # (--kernel-trace only, one counter per pass), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-#   usage: bash tools/make_profiles.sh <tag>            (e.g. r3)
+#   usage: bash tools/make_profiles.sh <tag> [pmc]      (e.g. r3; `pmc`: only the counter passes and the bench lines that quote them)
 set -u
 TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/art; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/art; ONLY=${2:-all}
+if [ "$ONLY" = all ]; then rm -rf $OUT; fi
+mkdir -p $OUT
 pmc() {   # model qtype out-json
     for c in FETCH_SIZE WRITE_SIZE; do
-        timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
+        # (one step per graph launch: rocprofv3 1.1's counter collection crashes on the 260-node graphs of the default four steps per launch;
+        # and it segfaults now and then at start-up whatever the workload: up to three tries)
+        for try in 1 2 3; do
+            rm -rf $OUT/pmc_$1_$c
+            LMRS_STEPS_PER_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
+            ls $OUT/pmc_$1_$c/*/*counter_collection.csv > /dev/null 2>&1 && break
+        done
     done
     f=$(ls $OUT/pmc_$1_FETCH_SIZE/*/*counter_collection.csv | head -1); w=$(ls $OUT/pmc_$1_WRITE_SIZE/*/*counter_collection.csv | head -1)
     python tools/pmc_summary.py "$f" "$w" $3 $1 $2
@@ -19,6 +27,7 @@ pmc() {   # model qtype out-json
 }
 pmc llama-3.2-1b q8_0 $OUT/${TAG}_traffic_llama1b_q8.json
 pmc gemma-2-2b q4_0 $OUT/${TAG}_traffic_gemma2b_q4.json
+if [ "$ONLY" = pmc ]; then timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2>> $OUT/bench.err; exit 0; fi
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --cpu-steps 0 > $OUT/stats.log 2>&1
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv; rm -rf $OUT/stats

@@ -33,7 +33,7 @@ def main(fetch_csv, write_csv, out, model="llama-3.2-1b", qtype="q8_0"):
         wv = w.get(k, (0.0, 0))[0]
         res[k] = {"launches": n, "FETCH_SIZE_KiB_avg": round(fv, 1), "WRITE_SIZE_KiB_avg": round(wv, 1),
                   "hbm_bytes_per_launch": round((2 * fv + wv) * 1024)}
-    gemv = {k: v for k, v in res.items() if "gemv" in k}
+    gemv = {k: v for k, v in res.items() if "gemv" in k or "qkv_attn" in k}
     # one decode step of Llama-3.2-1B launches, per layer, one of each of the four layer GEMVs, and one classifier GEMV
     doc = {"note": __doc__.split("usage")[0].strip(), "model": model, "qtype": qtype, "kernel_source_hash": kernel_source_hash(), "kernels": res,
            "gemv_bytes_weighted_by_launch_count": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemv.values()) / max(1, sum(v["launches"] for v in gemv.values())))}

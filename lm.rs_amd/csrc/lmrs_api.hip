@@ -702,7 +702,9 @@ extern "C" int lmrs_p2p_connect(lmrs_ctx* c, const void* handles /* world x 64 b
             if (got != 1000.0f + (float)w) return fail("peer-to-peer handshake: the block of rank " + std::to_string(w) + " did not arrive");
         }
     }
+    c->qa_mode = qa_mode_for(c, 0);
     if (capture(c, true, &c->g_step)) { c->g_step = nullptr; c->eager = true; (void)hipGetLastError(); g_err.clear(); }
+    c->qa_mode = 0;
     return 0;
 }
 
@@ -967,7 +969,8 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         GemvArgs g = cls_args(c);
         c->cls_grid = f32w ? gemv_f32_grid(g, EPI_CLS) : gemv_grid(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS);
     }
-    if (!sharded && !f32w && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 0)) {
+    // (also the "cls" shard plan in its one-process-per-GPU form: there every GPU runs the layers whole, with the single-GPU launches)
+    if ((!sharded || (cls_only && !group_mode)) && !f32w && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 0)) {
         // qkv + attention as one launch (short contexts) when the model's qkv launch has a merged class for every prologue it uses
         GemvArgs q{}; q.q4 = c->q4; q.n = a.dim; q.o = c->att_dim + 2 * c->kv_dim;
         AttnArgs t{}; t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.gemma = a.model_type == LMRS_GEMMA;
@@ -988,7 +991,9 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         if (!c->dbg) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
     } else if (c->comm) {
         // RCCL collectives inside a captured graph: use it when the runtime accepts it, else enqueue every step
+        c->qa_mode = qa_mode_for(c, 0);
         if (capture(c, true, &c->g_step)) { c->g_step = nullptr; c->eager = true; (void)hipGetLastError(); g_err.clear(); }
+        c->qa_mode = 0;
     }
     // (peer-to-peer contexts capture their step graph in lmrs_p2p_connect, once the peers' arenas are known)
     if (sharded) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }

@@ -225,6 +225,14 @@ def main():
                     if model is not None:
                         model.close()
                     model = None
+            if model is None and want == "p2p" and os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1":
+                # one-device verification mode: RCCL refuses two ranks on one GPU, so the fallback every rank takes TOGETHER is a second
+                # peer-to-peer attempt (with LMRS_P2P_FAIL_RANK the first one fails on one rank only: the point of the exercise)
+                model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world)
+                handles = [None] * world
+                dist.all_gather_object(handles, model.p2p_handle())
+                model.p2p_connect(handles)
+                transport = "p2p (second attempt, all ranks together, after a failed connect)"
             if model is None:
                 uid = exchange_unique_id(dist, rank, lmrs_amd.comm_unique_id)
                 model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world, unique_id=uid)

@@ -678,6 +678,12 @@ extern "C" int lmrs_p2p_connect(lmrs_ctx* c, const void* handles /* world x 64 b
     if (!c || !handles) return fail("NULL argument");
     if (!c->p2p) return fail("not a peer-to-peer sharded context");
     if (c->p2p_ready) return fail("already connected");
+    {   // fault injection (tests): LMRS_P2P_FAIL_RANK=r makes the FIRST connect of rank r in this process fail, so that a launcher's
+        // "every rank falls back together" logic can be exercised
+        static int injected = 0;
+        const char* fr = getenv("LMRS_P2P_FAIL_RANK");
+        if (fr && atoi(fr) == c->rank && !injected++) return fail("peer-to-peer connect: injected failure (LMRS_P2P_FAIL_RANK)");
+    }
     HIP_OK(hipSetDevice(c->device));
     for (int w = 0; w < c->world; ++w) {
         if (w == c->rank) continue;

@@ -699,6 +699,25 @@ def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan
         print(f"rank {r}: step graph captured = {graph}")
 
 
+def test_bench_fallback_is_taken_by_all_ranks_together(tmp_path):
+    """The driver's multi-GPU launch (torch.distributed.run, one process per rank; here both ranks on ONE GPU over gloo) with a
+    peer-to-peer connect that fails on rank 1 only (LMRS_P2P_FAIL_RANK): rank 0, whose own connect succeeded, must drop its context
+    too, both ranks must take the fallback branch together, and the run must complete with token parity.  (On one device the
+    fallback is a second peer-to-peer attempt - RCCL refuses two ranks on one GPU; on a node it is the RCCL communicator.)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LMRS_BENCH_ONE_DEVICE="1", LMRS_P2P_FAIL_RANK="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29597",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--cpu-steps", "6"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert "second attempt" in d["roofline"]["transport"], d["roofline"]["transport"]
+    assert "injected failure" in r.stderr                                  # rank 1 reported why it could not connect
+    assert d["parity"]["tokens_equal"] and d["n_gpus"] == 2
+
+
 def test_rccl_path_with_one_rank(L):
     """The RCCL code path (communicator, all-gathers between the segments, graph capture) with world = 1."""
     img = S.build_image("mini-llama", S.Q8_0, seed=32)

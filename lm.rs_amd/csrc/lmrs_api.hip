@@ -995,6 +995,21 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         CK(capture(c, false, &c->g_layers));
         // from this position on a step uses the split attention (scores by key chunk, V by dim slice): graphs captured on first use
         if (!c->dbg) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
+        // every graph a call below that threshold can need - per qkv + attention mode the single-step graph and the multi-step one -
+        // is captured here rather than inside the first generate call that reaches the mode (a capture is milliseconds: on a
+        // 128-token run that crosses the wave -> workgroup switch it was 3 % of the run)
+        if (!c->dbg && c->qkv_att) {
+            for (int mode = 1; mode <= 2; ++mode) {
+                if (mode == 2 && c->qa_wave_T <= 0) continue;
+                if (mode == 1 && c->qa_wave_T >= c->qa_max_T) continue;
+                c->qa_mode = mode;
+                int rc = 0;
+                if (mode != qa_mode_for(c, 0)) rc = capture(c, true, &c->g_step_alt[mode]);
+                if (!rc && c->multi_k > 1) rc = capture(c, true, &c->g_multi[mode], c->multi_k);
+                c->qa_mode = 0;
+                CK(rc);
+            }
+        }
     } else if (c->comm) {
         // RCCL collectives inside a captured graph: use it when the runtime accepts it, else enqueue every step
         c->qa_mode = qa_mode_for(c, 0);

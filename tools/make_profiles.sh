@@ -13,14 +13,15 @@ mkdir -p $OUT
 pmc() {   # model qtype out-json
     for c in FETCH_SIZE WRITE_SIZE; do
         # (one step per graph launch: rocprofv3 1.1's counter collection crashes on the 260-node graphs of the default four steps per launch;
-        # and it segfaults now and then at start-up whatever the workload: up to three tries)
+        # and it segfaults now and then at start-up whatever the workload - or hangs: a pass that works takes 25 s, so 60 s per try, up to three tries)
         for try in 1 2 3; do
             rm -rf $OUT/pmc_$1_$c
-            LMRS_STEPS_PER_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
+            LMRS_STEPS_PER_GRAPH=1 timeout -k 5 60 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
             ls $OUT/pmc_$1_$c/*/*counter_collection.csv > /dev/null 2>&1 && break
         done
     done
-    f=$(ls $OUT/pmc_$1_FETCH_SIZE/*/*counter_collection.csv | head -1); w=$(ls $OUT/pmc_$1_WRITE_SIZE/*/*counter_collection.csv | head -1)
+    f=$(ls $OUT/pmc_$1_FETCH_SIZE/*/*counter_collection.csv 2>/dev/null | head -1); w=$(ls $OUT/pmc_$1_WRITE_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
+    if [ -z "$f" ] || [ -z "$w" ]; then echo "pmc $1: no counter data (rocprofv3 failed on every try)"; return; fi
     python tools/pmc_summary.py "$f" "$w" $3 $1 $2
     cp $3 profiles/                                   # bench.py reads profiles/*traffic*.json (matching model / qtype / source hash)
     rm -rf $OUT/pmc_$1_FETCH_SIZE $OUT/pmc_$1_WRITE_SIZE

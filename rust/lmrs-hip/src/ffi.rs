@@ -17,6 +17,10 @@ pub struct LmrsVision {
 pub struct LmrsProcessor {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct LmrsSampler {
+    _private: [u8; 0],
+}
 
 extern "C" {
     pub fn lmrs_create(file: *const u8, len: usize, device: c_int, out: *mut *mut LmrsCtx, bytes_consumed: *mut usize) -> c_int;
@@ -41,6 +45,11 @@ extern "C" {
     pub fn lmrs_processor_destroy(p: *mut LmrsProcessor);
     pub fn lmrs_processor_forward(p: *mut LmrsProcessor, out_patches: *const f32, total_floats: u32, new_shape: u32, patch_side: u32,
                                   w_crop: u32, h_crop: u32, out: *mut f32, n_embeds: *mut u32) -> c_int;
+
+    pub fn lmrs_sampler_create(vocab_size: u32, temperature: f32, top_p: f32, seed: u64, out: *mut *mut LmrsSampler) -> c_int;
+    pub fn lmrs_sampler_destroy(s: *mut LmrsSampler);
+    pub fn lmrs_sampler_sample(s: *mut LmrsSampler, logits: *mut f32, next: *mut u32) -> c_int;
+    pub fn lmrs_forward_sample(ctx: *mut LmrsCtx, token: u32, pos: u32, sampler: *mut LmrsSampler, next: *mut u32) -> c_int;
 }
 
 /// The reference panics (`assert!` / `expect`); the C ABI returns a status and a message.  Same behaviour for the caller.

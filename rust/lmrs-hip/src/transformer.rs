@@ -105,6 +105,10 @@ impl<'a> Transformer<'a> {
         new_pos
     }
 
+    pub(crate) fn ctx(&mut self) -> *mut LmrsCtx {
+        self.ctx
+    }
+
     /// The token loop of src/bin/chat.rs:188-222 at temperature 0, device-resident (one host sync per call): feeds `prompt`
     /// from position `start_pos`, then `n_new - 1` further steps feeding back the argmax; returns the `n_new` generated ids.
     pub fn generate_greedy(&mut self, prompt: &[u32], n_new: u32, start_pos: u32) -> Vec<u32> {

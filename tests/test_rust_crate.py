@@ -19,6 +19,7 @@ CMAP = {
     "const lmrs_args*": "*const TransformerArgs",
     "lmrs_vision*": "*mut LmrsVision", "lmrs_vision**": "*mut *mut LmrsVision",
     "lmrs_processor*": "*mut LmrsProcessor", "lmrs_processor**": "*mut *mut LmrsProcessor",
+    "uint64_t": "u64", "lmrs_sampler*": "*mut LmrsSampler", "const lmrs_sampler*": "*const LmrsSampler", "lmrs_sampler**": "*mut *mut LmrsSampler",
 }
 
 
@@ -61,7 +62,7 @@ def rust_externs():
 
 def test_every_extern_declaration_matches_the_header():
     c, r = c_prototypes(), rust_externs()
-    assert len(r) >= 17, sorted(r)
+    assert len(r) >= 21, sorted(r)
     for name, (rret, rargs) in r.items():
         assert name in c, f"{name} is declared in ffi.rs but not in include/lmrs_hip.h"
         cret, cargs = c[name]
@@ -77,7 +78,8 @@ def test_the_transformer_surface_of_the_reference_is_bound():
     r = rust_externs()
     for need in ("lmrs_create", "lmrs_destroy", "lmrs_get_args", "lmrs_forward", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_last_error",
                  "lmrs_vision_create", "lmrs_vision_forward", "lmrs_vision_destroy", "lmrs_processor_create", "lmrs_processor_forward",
-                 "lmrs_processor_destroy", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_generate_greedy", "lmrs_forward_argmax"):
+                 "lmrs_processor_destroy", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_generate_greedy", "lmrs_forward_argmax",
+                 "lmrs_sampler_create", "lmrs_sampler_destroy", "lmrs_sampler_sample", "lmrs_forward_sample"):
         assert need in r, need
 
 
@@ -91,6 +93,11 @@ def test_public_rust_api_has_the_reference_signatures():
               "pub fn get_embeddings(&self, tokens: &[u32]) -> Vec<f32>", "pub fn fill_kv_cache(&mut self, embeddings: &mut [f32], curr_pos: u32) -> u32",
               "impl<'a> Drop for Transformer<'a>", "pub args: TransformerArgs", "pub vocab_size: u32", "pub model_type: ModelType", "pub multimodal: bool"):
         assert s in sig(t), s
+    # reference src/sampler.rs:19, :109 (+ the device draw)
+    sm = open(os.path.join(CRATE, "src", "sampler.rs")).read()
+    for s in ("pub fn new(vocab_size: u32, temperature: f32, top_p: f32, seed: u64) -> Sampler", "pub fn sample(&mut self, logits: &mut [f32]) -> u32",
+              "impl Drop for Sampler", "pub fn forward_sample(&mut self, token: u32, pos: u32, sampler: &mut Sampler) -> u32"):
+        assert s in sig(sm), s
     # reference src/vision.rs:99, :244 and the two public header fields chat.rs reads
     for s in ("pub fn new(data: &'a [u8]) -> (VisionTransformer<'a>, usize)", "pub fn forward(&mut self, pixel_values: &[f32], num_crops: u32) -> (Vec<f32>, u32)",
               "pub patch_size: u32", "pub image_size: u32", "impl<'a> Drop for VisionTransformer<'a>"):

@@ -53,6 +53,8 @@ public:
     ~Sampler() { if (h_) lmrs_sampler_destroy(h_); }
     // sample(&mut self, logits: &mut [f32]) -> u32   (the logits are scaled / softmax-ed in place when temperature != 0)
     std::uint32_t sample(float* logits) { std::uint32_t next = 0; check(lmrs_sampler_sample(h_, logits, &next)); return next; }
+    // model.forward(token, pos) followed by sample(logits), the draw made on the device: only the token id comes back (lmrs_forward_sample)
+    std::uint32_t forward_sample(Transformer& model, std::uint32_t token, std::uint32_t pos) { return model.forward_sample(token, pos, h_); }
 
 private:
     lmrs_sampler* h_ = nullptr;

@@ -51,6 +51,8 @@ public:
         check(lmrs_fill_kv_cache(ctx_, embeddings.data(), static_cast<std::uint32_t>(embeddings.size() / args.dim), curr_pos, &np));
         return np;
     }
+    // forward + Sampler::sample with the logits staying in HBM (text.hpp: Sampler::forward_sample); `sampler`: a handle of lmrs_sampler_create.
+    std::uint32_t forward_sample(std::uint32_t token, std::uint32_t pos, lmrs_sampler* sampler) { std::uint32_t n = 0; check(lmrs_forward_sample(ctx_, token, pos, sampler, &n)); return n; }
     // chat.rs:188-222 at temperature 0.
     std::vector<std::uint32_t> generate_greedy(const std::vector<std::uint32_t>& prompt, std::uint32_t n_new, std::uint32_t start_pos = 0, double* seconds = nullptr) {
         std::vector<std::uint32_t> out(n_new);

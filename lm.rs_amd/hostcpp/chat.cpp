@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
             }
             const auto t0 = std::chrono::steady_clock::now();
             if (temperature == 0.0f) next = model.forward_argmax(token, pos);                     // :214-215, argmax fused on the device
-            else next = sampler.forward_sample(model, token, pos);                                // :214-215 with the logits staying in HBM (same token as sampler.sample(model.forward(..)))
+            else next = sampler.sample(model.forward(token, pos));                                // (sampler.forward_sample(model, token, pos) draws on the device: same token, measured 10 % slower per token - DESIGN.md §9)
             pos += 1;
             if (user_idx >= num_prompt_tokens && next != tokenizer.eos && !(mt == ModelType::GEMMA && next == 107)) {   // :218-222
                 std::fputs(tokenizer.decode(next).c_str(), stdout); std::fflush(stdout);

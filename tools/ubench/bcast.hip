@@ -132,11 +132,11 @@ static double run(const float* Q, const float* K, float* out, int grid, int nk) 
 
 int main() {
     const int nk = 96, NW = 8;                            // keys per wave per launch (the real kernel: 72 for 577 keys over 8 waves)
-    const size_t nq = (size_t)1536 * 64 * HS, nkf = (size_t)8 * 8 * 4 * nk * HS;
+    const size_t nq = (size_t)2560 * 64 * HS, nkf = (size_t)8 * 8 * 4 * nk * HS;
     std::vector<float> h(nq > nkf ? nq : nkf);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.0f - 0.5f;
     float *Q, *K, *out;
-    CK(hipMalloc(&Q, nq * 4)); CK(hipMalloc(&K, nkf * 4)); CK(hipMalloc(&out, (size_t)1536 * (NW * nk + 8) * 64 * 4));
+    CK(hipMalloc(&Q, nq * 4)); CK(hipMalloc(&K, nkf * 4)); CK(hipMalloc(&out, (size_t)2560 * (NW * nk + 8) * 64 * 4));
     CK(hipMemcpy(Q, h.data(), nq * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(K, h.data(), nkf * 4, hipMemcpyHostToDevice));
     const char* names[3] = {"L (ds_read_b128 broadcast)", "S (scalar loads)", "N (registers: VALU floor)"};
     for (int grid : {256, 512}) {
@@ -145,14 +145,17 @@ int main() {
             printf("%2d waves per CU  %-28s %8.1f us per launch  %6.1f ns per key per wave  -> score + output phases of the real kernel (2 x 72 keys per wave): %5.1f us\n",
                    grid / 256 * NW, names[m], us[m], us[m] * 1e3 / nk, us[m] / nk * 144.0);
     }
-    // the real launch has 320 workgroups (10 query blocks x 16 heads x 2 crops) on 256 CUs: 64 CUs carry two.  The same 320 x 8 waves x nk keys of
-    // work cut into 1280 workgroups of two waves (each wave 4 x the keys) spread evenly: what is the imbalance worth?
-    printf("\nthe real kernel's grid (320 workgroups of 8 waves) against the same work as 1280 workgroups of 2 waves:\n");
+    // the real launch has 320 workgroups (10 query blocks x 16 heads x 2 crops) of 8 waves on 256 CUs: 64 CUs carry two.  The same 2560 waves
+    // x nk keys as workgroups of 4, 2 and 1 waves - what the dispatcher spreads evenly: what is the imbalance worth?
+    printf("\nthe same 2560 waves x %d keys as 320 x 8 (the real grid), 640 x 4, 1280 x 2 and 2560 x 1 waves (us per launch; x 144 / %d for score + output):\n", nk, nk);
     {
         double a[3] = {run<0, 8>(Q, K, out, 320, nk), run<1, 8>(Q, K, out, 320, nk), run<2, 8>(Q, K, out, 320, nk)};
-        double b[3] = {run<0, 2>(Q, K, out, 1280, 4 * nk), run<1, 2>(Q, K, out, 1280, 4 * nk), run<2, 2>(Q, K, out, 1280, 4 * nk)};
-        for (int m = 0; m < 3; ++m) printf("  %-28s 320 x 8 waves: %7.1f us   1280 x 2 waves: %7.1f us   (x 144 / %d keys: %5.1f -> %5.1f us for score + output)\n",
-                                           names[m], a[m], b[m], nk, a[m] / nk * 144.0, b[m] / nk * 144.0);
+        double b[3] = {run<0, 4>(Q, K, out, 640, nk), run<1, 4>(Q, K, out, 640, nk), run<2, 4>(Q, K, out, 640, nk)};
+        double c[3] = {run<0, 2>(Q, K, out, 1280, nk), run<1, 2>(Q, K, out, 1280, nk), run<2, 2>(Q, K, out, 1280, nk)};
+        double d[3] = {run<0, 1>(Q, K, out, 2560, nk), run<1, 1>(Q, K, out, 2560, nk), run<2, 1>(Q, K, out, 2560, nk)};
+        for (int m = 0; m < 3; ++m)
+            printf("  %-28s %6.1f (%5.1f)  %6.1f (%5.1f)  %6.1f (%5.1f)  %6.1f (%5.1f)\n", names[m], a[m], a[m] / nk * 144.0, b[m], b[m] / nk * 144.0,
+                   c[m], c[m] / nk * 144.0, d[m], d[m] / nk * 144.0);
     }
     return 0;
 }

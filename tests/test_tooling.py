@@ -1,0 +1,61 @@
+"""Measurement tooling that the round's artefacts depend on (no GPU): the profile summaries bench.py quotes are the ones of the
+committed sources, the summary scripts reproduce the committed summaries from the committed raw statistics, and the next-round
+patches under tools/ubench still apply."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_rocprof_summary_is_reproducible_from_the_committed_statistics(tmp_path):
+    """tools/rocprof_summary.py over profiles/r3_kernel_stats.csv gives the per-step figure recorded in profiles/r3_rocprof_llama1b_q8.json."""
+    stats = os.path.join(ROOT, "profiles", "r3_kernel_stats.csv")
+    ref = json.load(open(os.path.join(ROOT, "profiles", "r3_rocprof_llama1b_q8.json")))
+    out = tmp_path / "s.json"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), stats, str(out), "llama-3.2-1b", "q8_0"], check=True, cwd=ROOT)
+    got = json.load(open(out))
+    for k in ("model", "qtype"):
+        assert got[k] == ref[k]
+    num = [k for k, v in ref.items() if isinstance(v, (int, float)) and not isinstance(v, bool)]
+    assert num, "the summary carries numeric fields"
+    for k in num:
+        assert got[k] == pytest.approx(ref[k], rel=1e-9), k
+
+
+def test_bench_reads_the_profile_summaries_when_the_source_hash_matches():
+    """bench.py reports roofline.traffic / frac_rocprof only from summaries stamped with the hash of the sources it runs; whatever the
+    state of the tree, the lookup must be consistent with the stamps."""
+    import bench
+    h = bench.kernel_source_hash()
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic_llama1b_q8.json")))
+    rp = json.load(open(os.path.join(ROOT, "profiles", "r3_rocprof_llama1b_q8.json")))
+    t = bench.pmc_traffic("llama-3.2-1b", "q8_0")
+    r = bench.rocprof_family_us("llama-3.2-1b", "q8_0")
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_llama1b_q8.json")))[-1]
+    if tr["kernel_source_hash"] == h and newest.endswith("r3_traffic_llama1b_q8.json"):
+        assert t is not None and t > 1e7
+    if tr["kernel_source_hash"] != h:
+        assert t is None or t > 0          # (an older summary with a matching hash may exist; never a mismatching one)
+    if rp["kernel_source_hash"] == h:
+        assert r is not None and 300 < r < 700
+    assert bench.pmc_traffic("llama-3.2-1b", "q4_0") is None or bench.pmc_traffic("llama-3.2-1b", "q4_0") > 0
+
+
+@pytest.mark.parametrize("patch", sorted(glob.glob(os.path.join(ROOT, "tools", "ubench", "*.patch"))))
+def test_ubench_patches_name_existing_files(patch):
+    """The patches under tools/ubench are work items kept as diffs: the next-round one must still apply to the tree; older
+    experiment records must at least point at files that exist."""
+    txt = open(patch).read()
+    targets = [ln[6:].split("\t")[0].strip() for ln in txt.splitlines() if ln.startswith("+++ b/")]
+    assert targets, patch
+    for t in targets:
+        assert os.path.exists(os.path.join(ROOT, t)), t
+    if os.path.basename(patch) == "vis_attention_scalar_rows.patch" and os.path.isdir(os.path.join(ROOT, ".git")):
+        r = subprocess.run(["git", "apply", "--check", patch], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -194,7 +194,7 @@ def main():
     prompt = S.prompt_tokens(cfg, W, 1234)
     t_build = time.time() - t0
 
-    def run_once(plan=None, transport_override=None):
+    def run_once(plan=None, transport_override=None, emit=True):
         """One configuration of the job: build the context(s), warm up, time K steps, report.  plan: None = the library's own choice
         (LMRS_SHARD_PLAN if the caller set it), "tp" / "cls" = forced for this run; transport_override: "rccl" / "p2p"."""
         if plan is not None:
@@ -213,6 +213,8 @@ def main():
                 ok = 1
                 try:
                     model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world)
+                    if os.environ.get("LMRS_BENCH_FAIL_RANK") == str(rank):      # test hook of THIS launcher: this rank's first connect fails
+                        model.debug_inject(0)
                     handles = [None] * world
                     dist.all_gather_object(handles, model.p2p_handle())
                     model.p2p_connect(handles)
@@ -227,7 +229,7 @@ def main():
                     model = None
             if model is None and want == "p2p" and os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1":
                 # one-device verification mode: RCCL refuses two ranks on one GPU, so the fallback every rank takes TOGETHER is a second
-                # peer-to-peer attempt (with LMRS_P2P_FAIL_RANK the first one fails on one rank only: the point of the exercise)
+                # peer-to-peer attempt (with LMRS_BENCH_FAIL_RANK the first one fails on one rank only: the point of the exercise)
                 model = lmrs_amd.Transformer(img, device=local_rank, rank=rank, world=world)
                 handles = [None] * world
                 dist.all_gather_object(handles, model.p2p_handle())
@@ -442,17 +444,29 @@ def main():
                            "image_bytes": int(img.size), "build_image_s": round(t_build, 1)},
                 "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "prefill": prefill, "vision": vision,
             }
-            print(json.dumps(out), flush=True)
+            if sharded:          # what moved the slices, and how many ranks RCCL itself counted (0: the peer-to-peer transport, no communicator)
+                out["transport"] = transport; out["rccl_nranks"] = model.comm_ranks()
+            if emit:
+                print(json.dumps(out), flush=True)
         model.close()
         return out
 
-    out = run_once()
-    # LMRS_BENCH_BOTH_PLANS=1 (N > 1): a second line for the configuration north_star names - every weight matrix row-split ("tp"),
-    # slices exchanged by RCCL all-gathers over xGMI - next to the library's own choice above (for the small models: "cls" over the
-    # peer-to-peer transport), so that one multi-GPU run yields both.
-    if os.environ.get("LMRS_BENCH_BOTH_PLANS") == "1" and dist is not None:
+    if dist is None or os.environ.get("LMRS_SHARD_PLAN") or os.environ.get("LMRS_BENCH_SINGLE_PLAN") == "1" or force_dist:
+        out = run_once()
+    else:
+        # N > 1.  The headline line is the configuration north_star names: every weight matrix row-split ("tp"), slices exchanged by
+        # RCCL all-gathers over xGMI.  The library's OWN choice for this model and world size (for the small models plan "cls" over the
+        # peer-to-peer push transport) is measured in the same job and rides along as `library_choice`, so that one
+        # run yields both (LMRS_BENCH_SINGLE_PLAN=1 / LMRS_SHARD_PLAN=...: one configuration only).
+        lib_out = run_once(emit=False)
         barrier()
-        run_once(plan="tp", transport_override=None if os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1" else "rccl")   # (RCCL refuses two ranks on one device)
+        one_dev = os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1"                      # (RCCL refuses two ranks on one device)
+        out = run_once(plan="tp", transport_override=None if one_dev else "rccl", emit=False)
+        if rank == 0:
+            out["library_choice"] = {k: lib_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
+            out["library_choice"]["parallelism"] = lib_out["config"]["parallelism"]
+            out["library_choice"]["roofline"] = {k: lib_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}
+            print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return out

@@ -88,6 +88,9 @@ int lmrs_p2p_connect(lmrs_ctx* ctx, const void* handles);
 int lmrs_shard_plan(const lmrs_args* args, int rank, int world, int* plan10);
 /* 1: the sharded step is one captured hipGraph (RCCL inside); 0: enqueued call by call; -1: not an RCCL shard.  No reference counterpart. */
 int lmrs_shard_uses_graph(const lmrs_ctx* ctx);
+/* Ranks of the context's RCCL communicator as RCCL itself counts them (ncclCommCount); 0: the context has no communicator (one GPU, or
+ * the peer-to-peer transport); -1: error.  Measurement aid: lets a benchmark record that the all-gathers really spanned N ranks. */
+int lmrs_comm_ranks(const lmrs_ctx* ctx);
 
 /* Verification aid (no reference counterpart): `world` row shards of one model as `world` contexts on ONE device,
  * exchanged by device-to-device copies instead of RCCL, so the sharding can be checked bit for bit on a 1-GPU box. */
@@ -184,6 +187,13 @@ int lmrs_debug_timeline(lmrs_ctx* ctx, unsigned long long* out, int max_nodes, i
 /* Verification aid (no reference counterpart; the reference's key_cache / value_cache are private, transformer.rs:302-303): one row of
  * the KV cache as the reference lays it out (which: 0 key, 1 value; kv_dim floats of `layer` at `pos`). */
 int lmrs_debug_kv(lmrs_ctx* ctx, int which, uint32_t layer, uint32_t pos, float* out);
+/* Fault injection for the tests of the multi-GPU paths (no reference counterpart; explicit calls, nothing is read from the environment):
+ *   what = 0: the next lmrs_p2p_connect of this context fails ("injected failure"), so that a launcher's "every rank falls back
+ *             together" logic can be exercised;
+ *   what = 1: a row-sharded context enqueues its steps eagerly from now on and spins `b` microseconds on the device right after the
+ *             exchange that follows segment `a` of every step (4 * n_layers = the argmax partials) - a peer that runs ahead then pushes
+ *             its next block while this shard has not consumed the current one. */
+int lmrs_debug_inject(lmrs_ctx* ctx, int what, int a, int b);
 /* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos` (the byte model of SURVEY.md §8d;
  * measurement aid, no reference counterpart). */
 int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);

@@ -27,8 +27,8 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv",
-    "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_p2p_handle", "lmrs_p2p_connect",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv", "lmrs_debug_inject",
+    "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_comm_ranks", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
     "lmrs_tokenizer_create", "lmrs_tokenizer_destroy", "lmrs_tokenizer_info", "lmrs_tokenizer_encode", "lmrs_tokenizer_decode",
@@ -69,10 +69,11 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        path = os.environ.get("LMRS_LIB", LIB_PATH)          # (A/B builds of the same sources: tools/ab_bench.sh)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the HIP extension is mandatory; there is no CPU fallback)")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         vp, u32, sz, f32p = C.c_void_p, C.c_uint32, C.c_size_t, C.POINTER(C.c_float)
         L.lmrs_last_error.restype = C.c_char_p
         L.lmrs_create.argtypes = [vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
@@ -98,6 +99,7 @@ def lib():
         L.lmrs_debug_timeline.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
         L.lmrs_shard_plan.argtypes = [C.POINTER(TransformerArgs), C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.lmrs_shard_uses_graph.argtypes = [vp]
+        L.lmrs_comm_ranks.argtypes = [vp]
         L.lmrs_group_create.argtypes = [vp, sz, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
         L.lmrs_group_forward.argtypes = [C.POINTER(vp), C.c_int, u32, u32, C.POINTER(f32p), C.POINTER(u32)]
         L.lmrs_vision_create.argtypes = [vp, sz, C.c_int, C.POINTER(vp), C.POINTER(sz)]
@@ -122,6 +124,7 @@ def lib():
         L.lmrs_forward_sample.argtypes = [vp, u32, u32, vp, C.POINTER(u32)]
         L.lmrs_op_sample_mult.argtypes = [C.c_int, vp, sz, C.c_float, C.c_float, C.POINTER(u32)]
         L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
+        L.lmrs_debug_inject.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.lmrs_p2p_handle.argtypes = [vp, vp]
         L.lmrs_p2p_connect.argtypes = [vp, vp]
         L.lmrs_bench_step.argtypes = [vp, u32, C.c_int, vp, vp, vp]
@@ -213,6 +216,10 @@ class Transformer:
         _chk(lib().lmrs_debug_kv(self._h, which, layer, pos, _p(out)))
         return out
 
+    def debug_inject(self, what: int, a: int = 0, b: int = 0) -> None:
+        """Fault injection for the multi-GPU tests (include/lmrs_hip.h: lmrs_debug_inject)."""
+        _chk(lib().lmrs_debug_inject(self._h, what, a, b))
+
     def p2p_handle(self) -> bytes:
         """Peer-to-peer sharded context: the 64-byte IPC handle of this rank's exchange arena (send it to every peer)."""
         buf = C.create_string_buffer(64)
@@ -223,6 +230,10 @@ class Transformer:
         """handles: the `world` handles in rank order."""
         blob = b"".join(handles)
         _chk(lib().lmrs_p2p_connect(self._h, C.create_string_buffer(blob, len(blob))))
+
+    def comm_ranks(self) -> int:
+        """ranks of the RCCL communicator (ncclCommCount); 0: none (one GPU / peer-to-peer transport)"""
+        return lib().lmrs_comm_ranks(self._h)
 
     def shard_uses_graph(self) -> int:
         return lib().lmrs_shard_uses_graph(self._h)

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "../../include/lmrs_hip.h"
+#include "lmrs_aql.h"
 #include "lmrs_format.h"
 #include "lmrs_kernels.h"
 
@@ -108,7 +109,13 @@ struct lmrs_ctx {
     // replays g_multi[mode] while multi_k steps remain inside one mode
     int multi_k = 1; hipGraphExec_t g_multi[3] = {nullptr, nullptr, nullptr};
     // ---- final argmax folded into the classifier launch (ClsTail): packed partials
-    bool cls_tail = false; unsigned long long* part_pk = nullptr;
+    bool cls_tail = false; unsigned long long* part_pk = nullptr; unsigned* cls_seq = nullptr;
+    // ---- the step as hand-written AQL packets on an HSA queue (lmrs_aql.h): one program per qa_mode, recorded on first use;
+    // lmrs_generate_greedy submits whole runs of steps through them (LMRS_AQL=0: hipGraph replays as before)
+    int inj_fail_connect = 0, inj_stall_seg = -1; long long inj_stall_ticks = 0;      // lmrs_debug_inject
+    bool aql_on = false; int aql_fence = 1; AqlProgram* aql_prog[3] = {nullptr, nullptr, nullptr};
+    // three-part launch (launch_qkv_attn_wo, wave form only): per-layer granules of the quantised attention output
+    bool wo_merged = false; unsigned long long* qgran = nullptr;
 
     template <class T> T* alloc(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -120,6 +127,7 @@ struct lmrs_ctx {
 namespace {
 
 __global__ void advance_pos_kernel(DevState* st, unsigned* seq) { st->pos += 1; st->step_count += 1; *seq += 1u; }
+__global__ void stall_kernel(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32); }   // lmrs_debug_inject
 
 size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -234,6 +242,16 @@ int enqueue_layer(lmrs_ctx* c, int l) {
         // 1 + 2 as ONE launch: the attention workgroups poll the granules the qkv workgroups write (launch_qkv_attn)
         g.gran = c->gran + (size_t)l * (c->att_dim + 2 * c->kv_dim); g.seq = c->seq;
         t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+        if (c->qa_mode == 2 && c->wo_merged) {
+            // 1 + 2 + 3 as ONE launch (launch_qkv_attn_wo): the wo workgroups poll the attention output the head pairs publish quantised
+            GemvArgs w = g;
+            w.gran = nullptr; w.wq = L.wo; w.ws = L.so; w.n = c->att_dim; w.o = a.dim; w.xin = nullptr; w.rms_w = nullptr; w.out = c->x;
+            w.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+            const size_t qn = (size_t)c->att_dim / 4 + c->att_dim / 128;
+            HIP_OK(launch_qkv_attn_wo(g, PRO_RMS_QUANT, t, w, c->qgran + (size_t)l * qn, c->err, c->stream));
+            g.gran = nullptr; g.seq = nullptr;
+            goto after_wo;
+        }
         HIP_OK(launch_qkv_attn(g, pending ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, t, c->err, c->qa_max_T, c->qa_mode == 2, c->stream));
         g.gran = nullptr; g.seq = nullptr;
     } else {
@@ -252,6 +270,7 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
     set_launch_tag(7);
     if (gemma && !c->gemma_fused) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
+after_wo:
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
     g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -302,6 +321,7 @@ GemvArgs cls_args(lmrs_ctx* c) {
     if (c->world > 1 || c->comm) {          // sharded: this shard's [values | indices] block of the gathered partials
         g.part_val = c->part + (size_t)c->rank * 2 * c->cls_grid;
         g.part_idx = reinterpret_cast<int*>(c->part + (size_t)c->rank * 2 * c->cls_grid) + c->cls_grid;
+        if (c->p2p && !getenv("LMRS_SHARD_SINGLE_PARTIALS")) { g.part_par = c->xseq + c->ex_slot; g.part_par_floats = (int)((size_t)c->world * 2 * kMaxArgmaxParts); }   // the exchange enqueued next takes this slot
     } else { g.part_val = c->part_val; g.part_idx = c->part_idx; }
     g.softcap_rows = a.model_type == LMRS_GEMMA ? (int)a.dim : 0;
     if (c->gemma_fused) { g.xin = c->x2; g.delta = c->tmp; g.add_w = c->layers[a.n_layers - 1].rms_post_ffn; g.xout = c->x; }
@@ -328,7 +348,7 @@ int enqueue_step(lmrs_ctx* c) {
     ArgmaxArgs m{};
     m.part_val = c->part_val; m.part_idx = c->part_idx; m.n_part = c->cls_grid; m.n_groups = 1; m.group_stride = 0; m.logits = c->logits; m.tail_row = unwritten_tail(c); m.tokens = c->tokens; m.st = c->st; m.seq = c->seq; m.emb = embed_args(c);
     if (c->cls_tail) {                                          // one GPU: the classifier's last-arriving workgroup finishes the step itself
-        g.has_tail = 1; g.tail.part_pk = c->part_pk; g.tail.err = c->err; g.tail.m = m;
+        g.has_tail = 1; g.tail.part_pk = c->part_pk; g.tail.err = c->err; g.tail.cls_seq = c->cls_seq; g.tail.m = m;
         HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS, c->stream));
         return 0;
     }
@@ -357,7 +377,7 @@ int enqueue_step(lmrs_ctx* c) {
 //     their workgroups re-quantising it.  Q4_0 models and LMRS_SHARD_F32_PAYLOAD=1: f32 slices.
 //   * tmp slices (fully row-split form) and the argmax partials: f32 / raw.
 // ------------------------------------------------------------------------------------------------
-struct ExchangeDesc { char* buf; size_t bytes, stride; const float* qsrc; size_t qn; };   // bytes valid per shard, blocks `stride` bytes apart (in place); qsrc: f32 slice still to be quantised into this shard's block
+struct ExchangeDesc { char* buf; size_t bytes, stride; const float* qsrc; size_t qn; size_t par = 0; };   // par > 0: double-buffered block, halves `par` bytes apart (exchange_push_kernel picks the half by its sequence number)   // bytes valid per shard, blocks `stride` bytes apart (in place); qsrc: f32 slice still to be quantised into this shard's block
 static bool shard_split_out() { static const bool v = getenv("LMRS_SHARD_SPLIT_OUT") != nullptr; return v; }
 // Which matrices to split over `world` GPUs.  Row-splitting a layer's matrices costs two exchanges per layer (four in the fully split
 // form): pure latency, a few microseconds each, every layer of every token.  It pays only when the gate / up / down stream a shard no
@@ -375,6 +395,9 @@ static bool shard_plan_cls_only(const lmrs_args& a, int world) {
 
 int n_segments(const lmrs_ctx* c) { return 4 * (int)c->args.n_layers + 2; }
 
+static size_t part_half_floats(const lmrs_ctx* c) { return (size_t)c->world * 2 * kMaxArgmaxParts; }
+// (LMRS_SHARD_SINGLE_PARTIALS=1: the single buffer of rounds 2-3, kept so that test_push_exchange_with_a_stalled_peer can be shown to fail without the halves)
+static bool part_double(const lmrs_ctx* c) { static const bool single = getenv("LMRS_SHARD_SINGLE_PARTIALS") != nullptr; return c->p2p && !single; }
 ExchangeDesc exchange_after(lmrs_ctx* c, int seg) {
     const int L4 = 4 * (int)c->args.n_layers;
     const ExchangeDesc none{nullptr, 0, 0, nullptr, 0};
@@ -387,7 +410,11 @@ ExchangeDesc exchange_after(lmrs_ctx* c, int seg) {
             default: return c->rep_out ? none : f32s(c->tmp, (size_t)c->dim_l);
         }
     }
-    if (seg == L4) return f32s(c->part, (size_t)2 * c->cls_grid);
+    if (seg == L4) {                                             // peer-to-peer: the partials are double-buffered (ArgmaxArgs::part_par)
+        ExchangeDesc e = f32s(c->part, (size_t)2 * c->cls_grid);
+        if (part_double(c)) e.par = part_half_floats(c) * 4;
+        return e;
+    }
     return none;
 }
 
@@ -474,6 +501,7 @@ int run_segment(lmrs_ctx* c, int seg) {
     ArgmaxArgs m{};
     m.part_val = c->part; m.part_idx = reinterpret_cast<const int*>(c->part) + c->cls_grid; m.n_part = c->cls_grid;
     m.n_groups = c->world; m.group_stride = 2 * c->cls_grid;
+    if (part_double(c) && c->ex_slot > 0) { m.part_par = c->xseq + (c->ex_slot - 1); m.part_par_floats = (int)part_half_floats(c); }     // the slot of the partials exchange just enqueued
     m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.seq = c->seq; m.emb = embed_args(c); m.tail_row = unwritten_tail(c);
     HIP_OK(launch_argmax_final(m, c->stream));
     return 0;
@@ -494,6 +522,7 @@ int enqueue_step_sharded(lmrs_ctx* c, bool layers_only = false) {
         if (run_segment(c, s)) return -1;
         const ExchangeDesc e = exchange_after(c, s);
         if (e.buf && enqueue_exchange(c, e)) return -1;
+        if (e.buf && s == c->inj_stall_seg) hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, c->stream, c->inj_stall_ticks);
     }
     if (layers_only) {          // the last layer's residual update, so that x holds the finished residual stream; advance the position
         const lmrs_args& a = c->args;
@@ -528,6 +557,7 @@ int enqueue_exchange(lmrs_ctx* c, const ExchangeDesc& e) {
         x.my_flags = c->xflags + (size_t)c->ex_slot * kMaxWorld; x.my_seq = c->xseq + c->ex_slot; x.err = c->xerr;
         { static const long long ms = getenv("LMRS_P2P_TIMEOUT_MS") ? atoll(getenv("LMRS_P2P_TIMEOUT_MS")) : 3000; x.timeout_ticks = ms * 100000ll; }   // 100 MHz wall clock
         ++c->ex_slot;
+        x.par_bytes = (int)e.par;
         if (e.qsrc) { x.qsrc = e.qsrc; x.qn = (int)e.qn; }      // the slice is quantised by the exchange kernel itself on its way out
         set_launch_tag(8);
         HIP_OK(launch_exchange_push(x, c->stream));
@@ -558,6 +588,28 @@ int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out, int n_steps = 1) {
     return 0;
 }
 
+// The launches of one decode step in form `mode` (qa_mode), recorded instead of enqueued and turned into AQL packets.  null: the
+// step cannot be expressed (a kernel the loader does not find, scratch memory): the context falls back to its graphs for good.
+AqlProgram* aql_step_program(lmrs_ctx* c, int mode) {
+    if (!c->aql_on) return nullptr;
+    if (c->aql_prog[mode]) return c->aql_prog[mode];
+    AqlRecorder rec;
+    const int keep = c->qa_mode;
+    aql_set_recorder(&rec);
+    c->qa_mode = mode; c->dbg_node = 0;
+    const int rc = enqueue_step(c);
+    c->qa_mode = keep;
+    aql_set_recorder(nullptr);
+    std::string why;
+    AqlProgram* p = rc ? nullptr : aql_program_create(c->device, rec, &why);
+    if (!p) {
+        c->aql_on = false;
+        if (getenv("LMRS_AQL_VERBOSE")) fprintf(stderr, "lmrs: AQL path off: %s\n", rc ? g_err.c_str() : why.c_str());
+        return nullptr;
+    }
+    return c->aql_prog[mode] = p;
+}
+
 // host->device copy of one tensor payload, optionally row-interleaved (dst row = 2*r + phase)
 int upload(lmrs_ctx* c, void* dst, const uint8_t* src, size_t bytes) {
     HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -576,7 +628,7 @@ int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end, int win_base = -1)
     DevState* hs = c->h_st + (c->h_st_next++ % kStateSlots);
     hs->pos = (int)pos; hs->prompt_end = (int)prompt_end; hs->step_count = 0; hs->win_base = win_base;
     HIP_OK(hipMemcpyAsync(c->st, hs, sizeof(DevState), hipMemcpyHostToDevice, c->stream));
-    if (c->qkv_att || c->cls_tail) HIP_OK(hipMemsetAsync(c->err, 0, 4, c->stream));                // the error word of the bounded in-launch waits starts every call from zero
+    if (c->qkv_att || c->cls_tail) HIP_OK(hipMemsetAsync(c->err, 0, 4, c->stream));   // (the three-part launch implies qkv_att)                // the error word of the bounded in-launch waits starts every call from zero
     return 0;
 }
 
@@ -629,6 +681,12 @@ extern "C" int lmrs_shard_plan(const lmrs_args* a, int rank, int world, int* pla
 
 // 1 if the sharded step of this context runs as one captured hipGraph (RCCL collectives inside), 0 if it is enqueued
 // call by call, -1 if the context is not an RCCL shard.
+extern "C" int lmrs_comm_ranks(const lmrs_ctx* c) {
+    if (!c) return -1;
+    if (!c->comm) return 0;
+    int n = 0;
+    return ncclCommCount(c->comm, &n) == ncclSuccess ? n : -1;
+}
 extern "C" int lmrs_shard_uses_graph(const lmrs_ctx* c) { return !c || !(c->comm || c->p2p) ? -1 : (c->g_step ? 1 : 0); }
 
 extern "C" int lmrs_create_sharded(const uint8_t* file, size_t len, int device, int rank, int world, const void* uid,
@@ -678,12 +736,7 @@ extern "C" int lmrs_p2p_connect(lmrs_ctx* c, const void* handles /* world x 64 b
     if (!c || !handles) return fail("NULL argument");
     if (!c->p2p) return fail("not a peer-to-peer sharded context");
     if (c->p2p_ready) return fail("already connected");
-    {   // fault injection (tests): LMRS_P2P_FAIL_RANK=r makes the FIRST connect of rank r in this process fail, so that a launcher's
-        // "every rank falls back together" logic can be exercised
-        static int injected = 0;
-        const char* fr = getenv("LMRS_P2P_FAIL_RANK");
-        if (fr && atoi(fr) == c->rank && !injected++) return fail("peer-to-peer connect: injected failure (LMRS_P2P_FAIL_RANK)");
-    }
+    if (c->inj_fail_connect) { c->inj_fail_connect = 0; return fail("peer-to-peer connect: injected failure (lmrs_debug_inject)"); }
     HIP_OK(hipSetDevice(c->device));
     for (int w = 0; w < c->world; ++w) {
         if (w == c->rank) continue;
@@ -850,7 +903,8 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     need(W * c->blk_att); need(W * c->blk_h);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
     c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8); need(512);
-    need(nl * (att_l + 2 * kv_l) * 8); need(256); need(256); need(kMaxArgmaxParts * 8); need(256);       // granules of the merged qkv + attention launch, step sequence number, error word
+    need(nl * (att / 4 + att / 128) * 8);                                              // granules of the three-part launch
+    need(nl * (att_l + 2 * kv_l) * 8); need(256); need(256); need(256); need(kMaxArgmaxParts * 8); need(256);       // granules of the merged qkv + attention launch, step sequence number, error word
     total += 4096;
     HCK(hipMalloc(reinterpret_cast<void**>(&c->arena), total));
     c->arena_bytes = total;
@@ -918,7 +972,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         // every buffer a peer writes into: one fine-grained (L2-uncached, system-coherent) allocation, same layout on every shard
         size_t xo = 0;
         auto xneed = [&](size_t b) { const size_t o = xo; xo += pad256(b); return o; };
-        const size_t o_att = xneed(att * 4), o_h = xneed(hid * 4), o_tmp = xneed(dim * 4), o_logits = xneed(V * 4), o_part = xneed(W * 2 * kMaxArgmaxParts * 4),
+        const size_t o_att = xneed(att * 4), o_h = xneed(hid * 4), o_tmp = xneed(dim * 4), o_logits = xneed(V * 4), o_part = xneed(2 * W * 2 * kMaxArgmaxParts * 4),
                      o_gqa = xneed(W * c->blk_att), o_gqh = xneed(W * c->blk_h), o_flags = xneed((size_t)kMaxExchangeSlots * kMaxWorld * 4), o_seq = xneed((size_t)kMaxExchangeSlots * 4), o_err = xneed(256);
         HCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->xarena), xo, hipDeviceMallocFinegrained));
         c->xarena_bytes = xo;
@@ -937,11 +991,11 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         c->gq_att = c->alloc<char>(W * c->blk_att); c->gq_h = c->alloc<char>(W * c->blk_h);
     }
     c->tokens = c->alloc<uint32_t>((size_t)a.seq_len + 8); c->st = c->alloc<DevState>(1);
-    c->seq = c->alloc<unsigned>(1); c->gran = c->alloc<unsigned long long>(nl * (att_l + 2 * kv_l)); c->err = c->alloc<int>(1);
+    c->seq = c->alloc<unsigned>(1); c->cls_seq = c->alloc<unsigned>(1); c->gran = c->alloc<unsigned long long>(nl * (att_l + 2 * kv_l)); c->err = c->alloc<int>(1);
     c->part_pk = c->alloc<unsigned long long>(kMaxArgmaxParts);
-    if (!c->seq || !c->gran || !c->err || !c->part_pk) { fail("arena overflow"); return cleanup(); }
+    if (!c->seq || !c->cls_seq || !c->gran || !c->err || !c->part_pk) { fail("arena overflow"); return cleanup(); }
     HCK(hipMemsetAsync(c->part_pk, 0, kMaxArgmaxParts * 8, c->stream));
-    HCK(hipMemsetAsync(c->seq, 0, 4, c->stream)); HCK(hipMemsetAsync(c->gran, 0, nl * (att_l + 2 * kv_l) * 8, c->stream)); HCK(hipMemsetAsync(c->err, 0, 4, c->stream));
+    HCK(hipMemsetAsync(c->seq, 0, 4, c->stream)); HCK(hipMemsetAsync(c->cls_seq, 0, 4, c->stream)); HCK(hipMemsetAsync(c->gran, 0, nl * (att_l + 2 * kv_l) * 8, c->stream)); HCK(hipMemsetAsync(c->err, 0, 4, c->stream));
     if (getenv("LMRS_DEBUG_TIMELINE")) { c->dbg = c->alloc<unsigned long long>(8 * 1024); if (c->dbg) HCK(hipMemsetAsync(c->dbg, 0, 8 * 1024 * 8, c->stream)); }
     c->stage = c->alloc<float>(c->stage_floats);
     if (!c->stage) { fail("arena overflow"); return cleanup(); }
@@ -986,8 +1040,27 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         if (c->qkv_att && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 1)) c->qa_wave_T = qkv_attn_wave_T((int)a.head_size);   // LMRS_QKV_ATT=1: workgroup form only
         if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = 0;                  // (its prefetch reads whole 64-row blocks of the caches)
     }
+    if (c->qkv_att && c->qa_wave_T > 0 && getenv("LMRS_WO_MERGED") && atoi(getenv("LMRS_WO_MERGED")) != 0) {
+        // ... and (LMRS_WO_MERGED=1, off by default) the wo GEMV in the same launch while the one-wave-per-head form lasts, when the shapes
+        // have a three-part class.  Measured in round 4 (bit-equal): 443 us per step against 426 for the separate wo launch - 433 with the
+        // wo workgroups' tile request delayed until the qkv rows' loads are through; the launch is as wide as its widest role (207 VGPRs:
+        // 512 of its 656 workgroups resident) and the polled hand-off costs what the boundary it replaces cost.
+        GemvArgs q{}; q.q4 = c->q4; q.n = a.dim; q.o = c->att_dim + 2 * c->kv_dim;
+        AttnArgs t{}; t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.gemma = a.model_type == LMRS_GEMMA;
+        GemvArgs w{}; w.q4 = c->q4; w.n = c->att_dim; w.o = a.dim;
+        if (!c->gemma_fused && qkv_attn_wo_supported(q, PRO_RMS_QUANT, t, w)) {
+            c->qgran = c->alloc<unsigned long long>(nl * (att / 4 + att / 128));
+            if (!c->qgran) { fail("arena overflow"); return cleanup(); }
+            HCK(hipMemsetAsync(c->qgran, 0, nl * (att / 4 + att / 128) * 8, c->stream));
+            c->wo_merged = true;
+        }
+    }
     if (!sharded) { const int k = getenv("LMRS_STEPS_PER_GRAPH") ? atoi(getenv("LMRS_STEPS_PER_GRAPH")) : 4; c->multi_k = k < 1 ? 1 : (k > 64 ? 64 : k); }   // (measured: 4 steps per launch +1.5 % on a 20-step run, no effect on long runs)
     c->cls_tail = !sharded && !f32w && V < (1u << 20) - 1 && !(getenv("LMRS_CLS_TAIL") && atoi(getenv("LMRS_CLS_TAIL")) == 0);
+    // hand-written AQL packets instead of graph replays for runs of decode steps (one GPU, quantised weights, the argmax folded in: every
+    // launch of such a step goes through the recordable launch macro)
+    c->aql_on = !sharded && !f32w && c->cls_tail && !getenv("LMRS_DEBUG_TIMELINE") && getenv("LMRS_AQL") && atoi(getenv("LMRS_AQL")) != 0;
+    c->aql_fence = getenv("LMRS_AQL_FENCE") ? atoi(getenv("LMRS_AQL_FENCE")) : 1;
     if (!sharded) {
         c->qa_mode = qa_mode_for(c, 0);
         CK(capture(c, true, &c->g_step));
@@ -1035,6 +1108,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->g_layers) (void)hipGraphExecDestroy(c->g_layers);
     for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : c->g_multi) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& p : c->aql_prog) aql_program_destroy(p);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) (void)hipHostFree(c->h_logits);
@@ -1358,8 +1432,28 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     }
     if (set_state(c, start_pos + (uint32_t)done, start_pos + (uint32_t)n_prompt)) return -1;
     HIP_OK(launch_embed(embed_args(c), c->stream));
+    double aql_seconds = 0.0;
     for (size_t s = done; s < steps;) {
         const uint32_t p = start_pos + (uint32_t)s;
+        if (c->aql_on && !c->dbg) {
+            // every step up to the split-attention threshold as one submission of hand-written AQL packets (lmrs_aql.h)
+            std::vector<AqlProgram*> run;
+            for (size_t e = s; e < steps; ++e) {
+                const uint32_t pe = start_pos + (uint32_t)e;
+                if (c->att_split_pos > 0 && (int)pe >= c->att_split_pos) break;
+                AqlProgram* prog = aql_step_program(c, qa_mode_for(c, pe));
+                if (!prog) break;
+                run.push_back(prog);
+            }
+            if (!run.empty() && c->aql_on) {
+                HIP_OK(hipStreamSynchronize(c->stream));
+                std::string why; double sec = 0.0;
+                if (aql_run(c->device, run.data(), run.size(), c->aql_fence, &sec, &why)) return fail("AQL step: " + why);
+                aql_seconds += sec;
+                s += run.size();
+                continue;
+            }
+        }
         const int K = c->multi_k;
         const bool split_soon = c->att_split_pos > 0 && (int)(p + K - 1) >= c->att_split_pos;
         if (K > 1 && c->g_step && !c->dbg && s + K <= steps && !split_soon && qa_mode_for(c, p) == qa_mode_for(c, p + K - 1)) {
@@ -1382,7 +1476,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
     if (n_new) memcpy(out_tokens, c->h_tok, (size_t)n_new * 4);
-    if (seconds) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *seconds = ms * 1e-3; }
+    if (seconds) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *seconds = ms * 1e-3 + aql_seconds; }
     return 0;
 }
 
@@ -1497,7 +1591,7 @@ extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9
             const int kind = tags[i] >= 0 && tags[i] < 9 ? tags[i] : 7;
             us9[kind] += (double)ms * 1e3; count9[kind] += 1;
             const double att_bytes = 2.0 * kv * 4 * ((double)pos + it + 3);                       // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
-            bytes9[kind] += kind == 1 ? att_bytes : wbytes[kind] + (kind == 0 && merged ? att_bytes : 0.0);   // merged launch: both under kind 0
+            bytes9[kind] += kind == 1 ? att_bytes : wbytes[kind] + (kind == 0 && merged ? att_bytes : 0.0) + (kind == 0 && qmode == 2 && c->wo_merged ? wbytes[2] : 0.0);   // merged launches: everything under kind 0
         }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -1534,6 +1628,21 @@ extern "C" int lmrs_debug_kv(lmrs_ctx* c, int which, uint32_t layer, uint32_t po
     return 0;
 }
 
+extern "C" int lmrs_debug_inject(lmrs_ctx* c, int what, int a, int b) {
+    if (!c) return fail("ctx is NULL");
+    if (what == 0) { c->inj_fail_connect = 1; return 0; }
+    if (what == 1) {
+        if (!(c->comm || c->p2p)) return fail("not a row-sharded context");
+        HIP_OK(hipSetDevice(c->device));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (c->g_step) { (void)hipGraphExecDestroy(c->g_step); c->g_step = nullptr; }
+        for (auto& g : c->g_step_long) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+        c->eager = true; c->inj_stall_seg = a; c->inj_stall_ticks = (long long)b * 100;          // 100 MHz wall clock
+        return 0;
+    }
+    return fail("unknown injection");
+}
+
 extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, double* algo_bytes) {
     if (!c) return fail("ctx is NULL");
     const lmrs_args& a = c->args;
@@ -1543,7 +1652,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (qa_mode_for(c, pos) && !(c->att_split_pos > 0 && (int)pos >= c->att_split_pos) ? 4 : 5)) * (int)a.n_layers + (c->cls_tail ? 1 : 2);
+    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (qa_mode_for(c, pos) && !(c->att_split_pos > 0 && (int)pos >= c->att_split_pos) ? (qa_mode_for(c, pos) == 2 && c->wo_merged ? 3 : 4) : 5)) * (int)a.n_layers + (c->cls_tail ? 1 : 2);
     return 0;
 }
 
@@ -1676,7 +1785,7 @@ extern "C" int lmrs_op_classifier_argmax(int device, const float* x, const float
     void *ppk = S.get(kMaxArgmaxParts * 8), *ptk = S.get(16);
     if (!ptk) return fail("hipMalloc failed");
     HIP_OK(hipMemset(ppk, 0, kMaxArgmaxParts * 8)); HIP_OK(hipMemset(ptk, 0, 16)); HIP_OK(hipMemset(dtok, 0, 16)); HIP_OK(hipMemset(dst, 0, sizeof(DevState)));
-    g.has_tail = 1; g.tail.part_pk = static_cast<unsigned long long*>(ppk); g.tail.err = static_cast<int*>(ptk) + 1; m.seq = static_cast<unsigned*>(ptk); g.tail.m = m;
+    g.has_tail = 1; g.tail.part_pk = static_cast<unsigned long long*>(ppk); g.tail.err = static_cast<int*>(ptk) + 1; m.seq = static_cast<unsigned*>(ptk); g.tail.cls_seq = static_cast<unsigned*>(ptk) + 2; g.tail.m = m;
     HIP_OK(launch_gemv(g, PRO_RMS_QUANT, EPI_CLS, nullptr));
     HIP_OK(hipMemcpy(tk, dtok, 8, hipMemcpyDeviceToHost));
     { int e2[2]; HIP_OK(hipMemcpy(e2, ptk, 8, hipMemcpyDeviceToHost)); if (e2[1]) return fail("classifier argmax: the folded form's consumer timed out"); }

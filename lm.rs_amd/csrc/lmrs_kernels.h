@@ -14,7 +14,9 @@ struct DevState {
     int win_base;     // >= 0: first position of a batched forward_layer call (Gemma window quirk, see attention_body); < 0: decode
 };
 
-enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3 };   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
+enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3,   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
+                // merged qkv + attention + wo launch: the quantised attention output arrives as {4 x int8, tag} / {scale, tag} granules written inside the same launch
+                PRO_PREQ_TAG = 4 };
 enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5,
                 // CLIP tower (batched GEMM only): + bias with q / sqrt(head) | + bias + residual | + bias, QuickGELU
                 EPI_VQKV = 6, EPI_BIAS_RESID = 7, EPI_BIAS_QGELU = 8,
@@ -33,6 +35,10 @@ struct EmbedArgs {
 struct ArgmaxArgs {
     const float* part_val; const int* part_idx; int n_part;
     int n_groups, group_stride;   // row-sharded classifier: n_groups shards of partials, group_stride entries apart (1 shard: 1, 0)
+    // peer-to-peer row-sharded step: the gathered partials are double-buffered by the parity of the exchange that delivered them
+    // (*part_par = exchanges finished on their slot): a shard that runs ahead pushes step s + 1 into the OTHER half while a slower peer
+    // still reads step s (with one exchange per step - plan "cls" - nothing else orders the two).  null: single buffer.
+    const unsigned* part_par; int part_par_floats;
     const float* logits;
     int tail_row;            // > 0: logits[tail_row ..] are never written by the classifier (vocab % 4 rows, functional.rs:183) and hold 0.0
     uint32_t* tokens; DevState* st;
@@ -47,7 +53,9 @@ struct ArgmaxArgs {
 struct ClsTail {
     unsigned long long* part_pk;   // [grid - 1] packed partials {value | nan flag, tag, index}
     int* err;                      // set if the consumer's bounded sweep gives up
-    ArgmaxArgs m;                  // part_val / part_idx / n_part unused here; m.seq (non-null) makes the tags
+    unsigned* cls_seq;             // count of finished classifier-tail launches: the tags are made of THIS counter, which nothing else bumps
+                                   // (the step counter m.seq is also bumped by layers-only steps: 2047 of them in a row would alias an 11-bit tag)
+    ArgmaxArgs m;                  // part_val / part_idx / n_part unused here
 };
 
 struct GemvArgs {
@@ -68,8 +76,12 @@ struct GemvArgs {
     const DevState* st;
     // EPI_QKV_TAG: gran[row] = {value, tag = *seq + 1}; seq = steps finished so far on this context (never reset)
     unsigned long long* gran; const unsigned* seq;
+    // PRO_PREQ_TAG: n/4 granules {4 x int8, tag} then n/128 granules {scale, tag}; err: set when a bounded poll gives up
+    const unsigned long long* gran_in; int* err;
+    int tag_sleep0, tag_sleep1;   // PRO_PREQ_TAG: s_sleep(16) rounds (~0.43 us each) before the weight tile is requested / before the first poll
     // EPI_CLS
     float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on (global) rows < softcap_rows
+    const unsigned* part_par; int part_par_floats;      // the partials go to the half the NEXT exchange of their slot will push: ((*part_par + 1) & 1) * part_par_floats (see ArgmaxArgs)
     int row_offset;          // global index of this launch's row 0 (row-sharded classifier)
     int has_tail; ClsTail tail;   // EPI_CLS: fold the final argmax into this launch (see ClsTail)
     unsigned long long* dbg; // optional: 8 wall-clock stamps (debug timeline)
@@ -107,10 +119,17 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 // rows of the earlier positions and poll the {value, tag} granules the GEMV workgroups of the same launch write (g.gran, g.seq).
 // max_T: longest context (pos + 1) the launch will ever see (sizes the LDS score vector).  hipErrorNotSupported: no merged class
 // for this shape - the caller launches the two kernels separately.
-struct QkvAttnArgs { GemvArgs g; AttnArgs t; int* err; };
+struct QkvAttnArgs { GemvArgs g; AttnArgs t; int* err; GemvArgs w; unsigned long long* qgran; };   // w / qgran: the wo GEMV of the three-part form (launch_qkv_attn_wo)
 bool qkv_attn_supported(const GemvArgs& g, int pro, const AttnArgs& t);
 int qkv_attn_wave_T(int head_size);       // longest context (pos + 1) of the one-wave-per-head form; 0: none for this head size
 hipError_t launch_qkv_attn(const GemvArgs& g, int pro, const AttnArgs& t, int* err, int max_T, bool wave, hipStream_t s);
+// ... and the wo GEMV as well (one-wave-per-head form only, head size 64, Q8_0): two heads - one 128-value quantisation group - share a
+// workgroup, quantise their outputs together (quantization.rs:44-67, the device functions of the PRO_QUANT prologue) and publish
+// them as {4 x int8, tag} / {scale, tag} granules (qgran: att_dim/4 + att_dim/128); the wo workgroups of the same launch, their weight
+// tile already in registers, poll the 4 KB quantised vector straight into LDS and run their rows.  w: the arguments of the separate
+// wo launch (w.xin unused).  hipErrorNotSupported: no class for this shape.
+bool qkv_attn_wo_supported(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w);
+hipError_t launch_qkv_attn_wo(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w, unsigned long long* qgran, int* err, hipStream_t s);
 // long contexts: scores by (head, 256-key chunk), softmax + V by (head, quarter of the dims); S: attention_split_scratch_floats(..)
 size_t attention_split_scratch_floats(int n_heads, int seq_len);
 hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks, hipStream_t s);
@@ -144,6 +163,7 @@ struct ExchangeArgs {
     unsigned* my_flags;           // my flag row of this slot (one word per source shard)
     unsigned* my_seq; int* err;
     int bytes, rank, world, slot; long long timeout_ticks;
+    int par_bytes;                // > 0: double-buffered block - this exchange moves the half (sequence number & 1) * par_bytes (see ArgmaxArgs)
     const float* qsrc; int qn;    // optional: f32 slice to quantise (Q8_0) into `local` first: [qn int8 | qn / 128 f32 scales]
 };
 hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s);

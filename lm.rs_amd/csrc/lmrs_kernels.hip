@@ -32,6 +32,7 @@
 #include <set>
 #include <utility>
 
+#include "lmrs_aql.h"
 #include "lmrs_device_math.h"
 #include "lmrs_kernels.h"
 #include "lmrs_stage.h"
@@ -291,7 +292,7 @@ __device__ __forceinline__ void argmax_tail(const ArgmaxArgs& a, float best, int
 // it replaced); a dedicated consumer workgroup polling from the start (its sweeps return behind the weight tiles of the GEMV workgroup
 // it shares a CU with - a CU answers its loads in request order: the last partial was seen 4 us late).  Nobody waits for workgroup 0;
 // its sweeps are bounded (err).
-__device__ __forceinline__ unsigned cls_tag(const GemvArgs& a) { return (*a.tail.m.seq + 1u) & 0x7ffu; }
+__device__ __forceinline__ unsigned cls_tag(const GemvArgs& a) { return (*a.tail.cls_seq + 1u) & 0x7ffu; }
 __device__ __forceinline__ void cls_publish(const GemvArgs& a, int bid, unsigned tag, float best, int best_i) {
     // index field: 0xfffff = "nothing above -inf in my rows" (best_i = 0x7fffffff); the host admits vocabularies below 2^20 - 1 only
     const unsigned hi = best_i < 0 ? (0x80000000u | (tag << 20)) : ((tag << 20) | (best_i == 0x7fffffff ? 0xfffffu : (unsigned)best_i));
@@ -320,6 +321,7 @@ __device__ __forceinline__ void cls_consumer(const GemvArgs& a, int nprod, const
     }
     if (a.dbg && threadIdx.x == 0) a.dbg[5] = wall_clock64();
     argmax_tail(a.tail.m, bv, bi, nan0, pre);
+    if (threadIdx.x == 0) *a.tail.cls_seq += 1u;                 // every workgroup of this launch read its tag at kernel start
     if (a.dbg && threadIdx.x == 0) a.dbg[7] = wall_clock64();
 }
 
@@ -409,9 +411,10 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     static_assert(L >= CL && (L & (L - 1)) == 0 && L <= 64, "bad L");
     LMRS_STAMP(0);
     const int bid = blockIdx.x, nblk = gridDim.x;
-    unsigned ctag = 0; TailPre tpre{};
+    unsigned ctag = 0; TailPre tpre{}; int pofs = 0;
     if constexpr (EPI == EPI_CLS) {
         if (a.has_tail) { ctag = cls_tag(a); if (bid == 0) tpre = tail_preload(a.tail.m); }     // (workgroup 0 will finish the step: ClsTail)
+        else if (a.part_par) pofs = (int)((*a.part_par + 1u) & 1u) * a.part_par_floats;          // double-buffered partials (ArgmaxArgs)
     }
     const int n = a.n, G = n / kGS;
     int8_t* xq = reinterpret_cast<int8_t*>(smem);                       // n bytes
@@ -585,10 +588,51 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
             for (int w2 = 1; w2 < kBlock / 64; ++w2)
                 if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
             best_i = cls_flag_nan_at_zero(a, best_i, bid);
-            if (!a.has_tail) { a.part_val[bid] = best; a.part_idx[bid] = best_i; }
+            if (!a.has_tail) { a.part_val[pofs + bid] = best; a.part_idx[pofs + bid] = best_i; }
             else cls_publish(a, bid, ctag, best, best_i);
         }
         if (a.has_tail && bid == 0) { __syncthreads(); cls_consumer(a, nblk, tpre, ctag); }     // workgroup-uniform
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-launch hand-off of a QUANTISED activation (merged qkv + attention + wo launch): the producers publish 128-value groups as 32
+// granules {4 x int8, tag} + one {scale, tag} (write-through stores: the data is the flag, as in the merged qkv + attention launch);
+// preq_poll brings the whole vector straight into the LDS image the GEMV rows read.  Every poll is bounded (err).
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned kTagSpinMax = 1u << 20;
+// the whole workgroup: quantised activation of N elements, granules -> xq[N] int8, xs[N/128] f32 in LDS (the caller's lds_barrier()
+// publishes it to the workgroup).  The producers are seconds of arithmetic away when the workgroup arrives: one long sleep first, then
+// a sweep every ~0.4 us.
+template <int N, int NTH>
+__device__ __forceinline__ void preq_poll(const GemvArgs& a, int8_t* xq, float* xs, unsigned tag, unsigned long long* dbg) {
+    constexpr int NI = N / 4, G = N / 128, SL = (NI + G + NTH - 1) / NTH;
+    const int t = threadIdx.x;
+    const unsigned long long* gi = a.gran_in;
+    for (int i = 0; i < a.tag_sleep1; ++i) __builtin_amdgcn_s_sleep(16);           // nothing can be there earlier
+    unsigned long long x[SL];
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) { const int k = t + i * NTH; x[i] = __hip_atomic_load(gi + (k < NI + G ? k : NI + G - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#pragma unroll
+        for (int i = 0; i < SL; ++i) ok = ok && (unsigned)(x[i] >> 32) == tag;
+        if (__syncthreads_and(ok)) break;                                          // (workgroup-uniform exit: every lane leaves with fresh values)
+        if (spins > kTagSpinMax || (spins & 1023) == 1023) {                       // bounded: report and finish with garbage instead of hanging (uniform decision)
+            const int e = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__syncthreads_or(e != 0 || spins > kTagSpinMax)) {
+                if (t == 0 && e == 0) __hip_atomic_store(a.err, 3000 + a.layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    if (dbg && t == 0) dbg[4] = wall_clock64();
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+        const int k = t + i * NTH;
+        if (k < NI) reinterpret_cast<unsigned*>(xq)[k] = (unsigned)x[i];
+        else if (k < NI + G) xs[k - NI] = __uint_as_float((unsigned)x[i]);
     }
 }
 
@@ -620,16 +664,18 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     const int o = a.o, n_pass = (o + R::RB - 1) / R::RB;
     const int8_t* wq = reinterpret_cast<const int8_t*>(a.wq);
     constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT;
+    constexpr bool PREQ = PRO == PRO_PREQ || PRO == PRO_PREQ_TAG;                      // the activation arrives quantised
 
-    unsigned ctag = 0; TailPre tpre{};
+    unsigned ctag = 0; TailPre tpre{}; int pofs = 0;
     if constexpr (EPI == EPI_CLS) {
         if (a.has_tail) { ctag = cls_tag(a); if (bid == 0) tpre = tail_preload(a.tail.m); }     // (workgroup 0 will finish the step: ClsTail)
+        else if (a.part_par) pofs = (int)((*a.part_par + 1u) & 1u) * a.part_par_floats;          // double-buffered partials (ArgmaxArgs)
     }
     int pos_pre = 0; unsigned tag_pre = 0;
     if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_TAG) pos_pre = a.st->pos;      // the kernel's first load: nothing it has to wait behind
-    if constexpr (EPI == EPI_QKV_TAG) tag_pre = *a.seq + 1u;
+    if constexpr (EPI == EPI_QKV_TAG || PRO == PRO_PREQ_TAG) tag_pre = *a.seq + 1u;
     float4 v[V::NP], nw[V::NP], dl[V::NP], aw[V::NP];
-    if constexpr (PRO != PRO_PREQ) {
+    if constexpr (!PREQ) {
         if constexpr (PRO == PRO_ADD_RMS_QUANT) { vec_load<N, false, NTH>(dl, a.delta); vec_load<N, false, NTH>(aw, a.add_w); }
         vec_load<N, false, NTH>(v, a.xin);
         if constexpr (HAS_RMS) vec_load<N, false, NTH>(nw, a.rms_w);
@@ -640,10 +686,14 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     asm volatile("" ::: "memory");               // keep the activation loads ahead of the weight tile in issue order
     // A CU returns vector-memory data in request order across its waves: without this barrier the activation loads of
     // the workgroup's later waves (L2 hits) queue behind the earlier waves' weight tiles (HBM misses).
-    if (PRO != PRO_PREQ && a.order_barrier) __builtin_amdgcn_s_barrier();
+    if (!PREQ && a.order_barrier) __builtin_amdgcn_s_barrier();
     // (waiting for the activation before issuing the tile, or issuing only part of it first, was measured: no gain)
     WTile<R::U> ta, tb;
     int pass = bid;                      // grid <= n_pass
+    if constexpr (PRO == PRO_PREQ_TAG) {
+        // the workgroups ahead in the grid (the qkv rows) are on the launch's critical path: this tile must not queue in front of theirs
+        for (int i = 0; i < a.tag_sleep0; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(pass));
     // (requesting the second pass's tile here as well - it would stream under the prologue - was measured slower on every model, Gemma's
     // 5 us folded prologue included: the more bytes are queued ahead of a workgroup's activation loads, the later they land)
@@ -657,7 +707,10 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     // chip has in flight, the later every workgroup's activation lands)
     __builtin_amdgcn_sched_barrier(0);           // the prologue's first wait must not be scheduled above the tile's loads
 
-    if constexpr (PRO == PRO_PREQ) {
+    if constexpr (PRO == PRO_PREQ_TAG) {
+        static_assert(PRO != PRO_PREQ_TAG || !Q4, "granule hand-off: Q8_0 activations");
+        preq_poll<N, NTH>(a, xq, xs, tag_pre, bid == 0 ? a.dbg : nullptr);         // (the weight tile requested above has landed long before)
+    } else if constexpr (PRO == PRO_PREQ) {
         constexpr int XB = Q4 ? N / 2 : N;
         for (int e = threadIdx.x * 16; e < XB; e += NTH * 16)
             *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(preq_bytes(a, e));
@@ -785,7 +838,7 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
             for (int w2 = 1; w2 < NTH / 64; ++w2)
                 if (rv[w2] > best || (rv[w2] == best && ri[w2] < best_i)) { best = rv[w2]; best_i = ri[w2]; }
             best_i = cls_flag_nan_at_zero(a, best_i, bid);
-            if (!a.has_tail) { a.part_val[bid] = best; a.part_idx[bid] = best_i; }
+            if (!a.has_tail) { a.part_val[pofs + bid] = best; a.part_idx[pofs + bid] = best_i; }
             else cls_publish(a, bid, ctag, best, best_i);
         }
         if constexpr (NTH == kBlock) {
@@ -794,9 +847,24 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     }
 }
 
+// Kernel-argument preload: a kernel's first instruction used to be an s_load of the argument block, and the activation loads could
+// only be issued when it came back - two dependent memory round trips between the launch and the first useful byte.  gfx950 can
+// deliver the first kernel-argument dwords in SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count, see the Makefile), but only
+// for SCALAR leading arguments, not for a struct passed by value: the pointers the first loads need are therefore repeated in front
+// of the argument struct (HotArgs, at most 7 pointers = 14 user SGPRs) and folded back into the struct's SSA copy here.
+struct HotPtrs { const float* xin; const void* wq; const float* ws; const float* rms_w; const DevState* st; const unsigned* seq; float* out; };
+__device__ __forceinline__ GemvArgs with_hot(const GemvArgs& a0, const float* xin, const void* wq, const float* ws, const float* rms_w, const DevState* st, const unsigned* seq, float* out) {
+    GemvArgs a = a0;
+    a.xin = xin; a.wq = wq; a.ws = ws; a.rms_w = rms_w; a.st = st; a.seq = seq; a.out = out;
+    return a;
+}
+#define LMRS_HOT_PARAMS const float* h_xin, const void* h_wq, const float* h_ws, const float* h_rms_w, const DevState* h_st, const unsigned* h_seq, float* h_out
+#define LMRS_HOT_OF(g) (g).xin, (g).wq, (g).ws, (g).rms_w, (g).st, (g).seq, (g).out
+
 template <int N, int L, int PRO, int EPI, int NTH, bool Q4 = false>
-__global__ __launch_bounds__(NTH) void gemv_static_kernel(const GemvArgs a) {
+__global__ __launch_bounds__(NTH) void gemv_static_kernel(LMRS_HOT_PARAMS, const GemvArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemvArgs a = with_hot(a0, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out);
     gemv_static_body<N, L, PRO, EPI, NTH, Q4>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -875,7 +943,8 @@ bool next_launch_events(hipEvent_t* a, hipEvent_t* b) {
 #define LMRS_LAUNCH_GRID(kern, grid3, nt, smem, s, ...)                                                     \
     do {                                                                                                    \
         hipEvent_t ea_, eb_;                                                                                \
-        if (next_launch_events(&ea_, &eb_)) hipExtLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, ea_, eb_, 0, __VA_ARGS__); \
+        if (aql_recorder()) aql_record(reinterpret_cast<const void*>(kern), grid3, (unsigned)(nt), smem, __VA_ARGS__);   /* the step is being recorded as AQL packets (lmrs_aql.h) */ \
+        else if (next_launch_events(&ea_, &eb_)) hipExtLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, ea_, eb_, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, __VA_ARGS__);                               \
     } while (0)
 #define LMRS_LAUNCH_NT(kern, grid, nt, smem, s, a) LMRS_LAUNCH_GRID(kern, dim3(grid), nt, smem, s, a)
@@ -888,7 +957,13 @@ static void allow_big_lds(const void* fn) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    if (done.insert({fn, dev}).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (done.insert({fn, dev}).second) {
+        // the limit covers static + dynamic LDS: a kernel with a few static bytes (the __syncthreads_and / _or helpers keep 256) is refused
+        // the full 160 KB, and the refusal would surface as `invalid argument` at its first launch above 64 KB
+        hipFuncAttributes fa{};
+        const size_t fixed = hipFuncGetAttributes(&fa, fn) == hipSuccess ? fa.sharedSizeBytes : 0;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - fixed));
+    }
 }
 
 static size_t gemv_smem(const GemvArgs& a, int pro) {
@@ -988,13 +1063,13 @@ hipError_t launch_gemv(const GemvArgs& a0, int pro, int epi, hipStream_t s, int 
     a.order_barrier = order_barrier; a.chain_spread = chain_spread;
     if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
     const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
-    if (epi == EPI_CLS && a.has_tail && (!a.tail.m.seq || !a.tail.err || !a.tail.part_pk || a.o + a.row_offset >= (1 << 20) - 1)) return hipErrorInvalidValue;
+    if (epi == EPI_CLS && a.has_tail && (!a.tail.cls_seq || !a.tail.err || !a.tail.part_pk || a.o + a.row_offset >= (1 << 20) - 1)) return hipErrorInvalidValue;
     const size_t smem = gemv_smem(a, pro);
     const StaticClass sc = static_class(a, pro, epi);
     if (sc.L) {
 #define X(n_, l_, p_, e_, nt_, q_)                                                                         \
         if (a.n == n_ && sc.L == l_ && pro == p_ && epi == e_ && sc.nt == nt_ && (a.q4 != 0) == q_) {      \
-            LMRS_LAUNCH_NT((gemv_static_kernel<n_, l_, p_, e_, nt_, q_>), grid, nt_, smem, s, a);            \
+            LMRS_LAUNCH_GRID((gemv_static_kernel<n_, l_, p_, e_, nt_, q_>), dim3(grid), nt_, smem, s, LMRS_HOT_OF(a), a);            \
             return hipGetLastError();                                                                      \
         }
         LMRS_STATIC_TABLE(X)
@@ -1171,7 +1246,6 @@ __device__ __forceinline__ float att_score_chain(f32x4v (&kk)[NG], __amdgpu_buff
 // the SAME launch as 8-byte {value, tag} granules (EPI_QKV_TAG); the lanes that need them poll the granules themselves, after
 // all K / V loads of the earlier positions have been issued.
 struct AttTag { const unsigned long long* gran; unsigned tag; int att_dim, kv_dim; int* err; };
-constexpr unsigned kTagSpinMax = 1u << 20;
 template <int HS, int NF, bool COH, bool PRE = false, bool GEMMA = false, bool ROT = false, bool TAG = false>
 __device__ __forceinline__ void attention_body(const AttnArgs& a, int h, int pos, char* smem, uint64_t etab, const AttPre& pre = AttPre(), const AttTag& tg = AttTag()) {
     static_assert(!PRE || HS / 2 <= kBlock, "one RoPE pair per lane");
@@ -1447,11 +1521,13 @@ template <int HS> struct WaveGeom {
 };
 constexpr int qa_wave_T(int hs) { return hs == 64 ? 128 : ((hs == 96 || hs == 128) ? 64 : 0); }   // 0: no wave class (Gemma's 256-wide heads)
 
+// (three-part launch: wo.qg != null - the head's outputs also leave quantised, see WoTag)
+struct WoTag { unsigned long long* qg; float* pair; int n_int; };    // qgran, the two waves' LDS exchange slot (2 floats), att_dim / 4
 template <int HS, bool GEMMA>
-__device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
+__device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg, const WoTag& wo = WoTag()) {
     using W = WaveGeom<HS>;
     constexpr int HS4 = W::HS4, ND = W::ND, NH2 = W::NH2, TW = W::TW, NPASS = W::NPASS, half = HS / 2;
-    const int lane = threadIdx.x;                                   // the caller retired threads 64..
+    const int lane = threadIdx.x & 63;                              // one wave per head (the caller retired the workgroup's other waves)
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul, kv_dim = a.n_kv_heads * HS;
     const int T = pos + 1, S = a.seq_len;
     float* qs = reinterpret_cast<float*>(smem);                     // HS: rotated query
@@ -1703,6 +1779,28 @@ __device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int 
         o[i] = o[i] + pr;
         if (d < HS) a.out[h * HS + d] = o[i];
     }
+    if constexpr (HS == 64) {
+        if (wo.qg) {
+            // heads 2g and 2g+1 are the two waves of this workgroup and together one 128-value quantisation group of the wo input:
+            // quantize (quantization.rs:44-67) with vec_quantize_q8's arithmetic - group maximum (order-free), scale = max / 127 by IEEE
+            // division, candidates by reciprocal with the exact redo - and publish it for the wo workgroups of this launch
+            const float x = o[0];
+            float m = wave64_max(fabsf(x));
+            if (lane == 0) wo.pair[h & 1] = m;
+            lds_barrier();                                               // the workgroup's two live waves
+            m = fmaxf(wo.pair[0], wo.pair[1]);
+            const float sc = m / 127.0f, inv = __builtin_amdgcn_rcpf(sc);
+            float dev = 0.0f;
+            int q = quant_q8_try(x, inv, dev);
+            if (quant_slow(m, dev)) q = quant_q8(x, sc);
+            const unsigned b = (unsigned)q & 0xffu;
+            unsigned w = b;
+            w |= (unsigned)__shfl_down((int)b, 1) << 8; w |= (unsigned)__shfl_down((int)b, 2) << 16; w |= (unsigned)__shfl_down((int)b, 3) << 24;
+            const unsigned long long tg64 = (unsigned long long)tg.tag << 32;
+            if ((lane & 3) == 0) __hip_atomic_store(wo.qg + (h * HS + lane) / 4, tg64 | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && (h & 1) == 0) __hip_atomic_store(wo.qg + wo.n_int + h / 2, tg64 | __float_as_uint(sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
 }
 
@@ -1710,8 +1808,10 @@ constexpr int qa_chunk(int hs) { return (8192 / hs) & ~31; }        // V rows pe
 template <int HS> struct QaGeom { static constexpr int CH = qa_chunk(HS), NF = (CH * (HS / 4) + kBlock - 1) / kBlock; };
 
 template <int N, int L, int PRO, bool Q4, int HS, bool GEMMA, bool WAVE>
-__global__ __launch_bounds__(kBlock) void qkv_attn_kernel(const QkvAttnArgs a) {
+__global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const QkvAttnArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    QkvAttnArgs a = a0;                                              // (kernel-argument preload: see gemv_static_kernel)
+    a.g = with_hot(a0.g, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out); a.t.st = h_st;
     const int nh = a.t.n_heads;
     if ((int)blockIdx.x < nh) {
         if constexpr (WAVE) { if (threadIdx.x >= 64) return; }     // one wave per head: no barrier below
@@ -1749,7 +1849,7 @@ static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t g
     if constexpr (qa_wave_T(HS) > 0) {
         if (wave) {
             size_t smem = WaveGeom<HS>::SMEM > gsmem ? WaveGeom<HS>::SMEM : gsmem;
-            LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), dim3(grid), kBlock, smem, s, a);
+            LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a);
             return hipGetLastError();
         }
     }
@@ -1757,7 +1857,7 @@ static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t g
     size_t smem = attention_smem(HS, qa_chunk(HS), max_T);
     if (gsmem > smem) smem = gsmem;
     if (smem > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>));
-    LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>), dim3(grid), kBlock, smem, s, a);
+    LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a);
     return hipGetLastError();
 }
 
@@ -1775,6 +1875,72 @@ hipError_t launch_qkv_attn(const GemvArgs& g0, int pro, const AttnArgs& t0, int*
     if (a.g.n == n_ && sc.L == l_ && pro == p_ && (a.g.q4 != 0) == q_ && t0.head_size == hs_ && (t0.gemma != 0) == gm_)  \
         return launch_qkv_attn_class<n_, l_, p_, q_, hs_, gm_>(a, grid, gsmem, max_T, wave, s);
     LMRS_QA_TABLE(X)
+#undef X
+    return hipErrorNotSupported;
+}
+
+// ------------------------------------------------------------------------------------------------
+// qkv + attention + wo as ONE launch (one-wave-per-head form, head size 64, Q8_0).  Workgroups [0, n_heads/2): two attention waves,
+// heads 2b and 2b+1 (the other waves retire); then the qkv GEMV workgroups (EPI_QKV_TAG); then the wo GEMV workgroups, which request
+// their weight tile, sleep through the qkv and attention phases, poll the quantised attention output (preq_poll) and run their rows
+// with the residual epilogue.  Nobody waits for a workgroup behind it in the grid and every workgroup is resident at once; all polls
+// are bounded.  Arithmetic: attention_wave_tag, vec_quantize_q8's, the static GEMV body - bit-identical to the separate launches.
+// ------------------------------------------------------------------------------------------------
+template <int N, int L, int PRO, int HS, int NW_, int LW>
+__global__ __launch_bounds__(kBlock) void qkv_attn_wo_kernel(LMRS_HOT_PARAMS, const QkvAttnArgs a0, const int n_qkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    QkvAttnArgs a = a0;                                              // (kernel-argument preload: see gemv_static_kernel)
+    a.g = with_hot(a0.g, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out); a.t.st = h_st; a.w.seq = h_seq;
+    const int npair = a.t.n_heads / 2, b = (int)blockIdx.x;
+    if (b < npair) {
+        if (threadIdx.x >= 128) return;                            // two waves: no workgroup barrier below except the pair's own
+        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const uint64_t etab = exp2f_tab_lane();
+        const int pos = a.t.st->pos;
+        const AttTag tg{a.g.gran, *a.g.seq + 1u, a.g.att_dim, a.g.kv_dim, a.err};
+        constexpr size_t WS = (WaveGeom<HS>::SMEM + 15) & ~(size_t)15;
+        const WoTag wo{a.qgran, reinterpret_cast<float*>(smem + 2 * WS), a.g.att_dim / 4};
+        attention_wave_tag<HS, false>(a.t, 2 * b + wv, pos, smem + wv * WS, etab, tg, wo);
+    } else if (b < npair + n_qkv) {
+        gemv_static_body<N, L, PRO, EPI_QKV_TAG, kBlock, false>(a.g, smem, b - npair, n_qkv);
+    } else {
+        gemv_static_body<NW_, LW, PRO_PREQ_TAG, EPI_RESID, kBlock, false>(a.w, smem, b - npair - n_qkv, (int)gridDim.x - npair - n_qkv);
+    }
+}
+
+// the three-part classes: (dim, lanes per qkv row, qkv prologue, head size, att_dim, lanes per wo row)
+#define LMRS_QAW_TABLE(X) X(2048, 32, PRO_RMS_QUANT, 64, 2048, 32)      /* Llama-3.2-1B Q8_0 */
+
+bool qkv_attn_wo_supported(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w) {
+    if (!qkv_attn_supported(g, pro, t) || g.q4 || w.q4 || t.gemma || (t.n_heads & 1) || qa_wave_T(t.head_size) <= 0 || w.n != t.n_heads * t.head_size) return false;
+    const StaticClass sc = static_class(g, pro, EPI_QKV), sw = static_class(w, PRO_PREQ, EPI_RESID);
+#define X(n_, l_, p_, hs_, nw_, lw_) if (g.n == n_ && sc.L == l_ && pro == p_ && t.head_size == hs_ && w.n == nw_ && sw.L == lw_ && sw.nt == kBlock && w.o == n_) return true;
+    LMRS_QAW_TABLE(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_qkv_attn_wo(const GemvArgs& g0, int pro, const AttnArgs& t0, const GemvArgs& w0, unsigned long long* qgran, int* err, hipStream_t s) {
+    static const int order_barrier = env_flag("LMRS_ORDER_BARRIER", 1);
+    if (!qkv_attn_wo_supported(g0, pro, t0, w0) || !g0.gran || !g0.seq || !err || !qgran) return hipErrorNotSupported;
+    QkvAttnArgs a{g0, t0, err, w0, qgran};
+    a.g.order_barrier = order_barrier; a.g.chain_spread = env_flag("LMRS_CHAIN_SPREAD", 1);
+    a.w.order_barrier = order_barrier; a.w.gran_in = qgran; a.w.err = err; a.w.seq = g0.seq;
+    a.w.tag_sleep0 = env_flag("LMRS_WO_SLEEP0", 0); a.w.tag_sleep1 = env_flag("LMRS_WO_SLEEP1", 6);
+    a.t.chunk = qa_chunk(t0.head_size);
+    const int n_qkv = gemv_grid(a.g, pro, EPI_QKV), n_wo = gemv_grid(a.w, PRO_PREQ, EPI_RESID);
+    const int grid = t0.n_heads / 2 + n_qkv + n_wo;
+#define X(n_, l_, p_, hs_, nw_, lw_)                                                                                     \
+    if (a.g.n == n_ && pro == p_ && t0.head_size == hs_ && a.w.n == nw_) {                                               \
+        size_t smem = 2 * ((WaveGeom<hs_>::SMEM + 15) & ~(size_t)15) + 16;                                              \
+        const size_t gs = gemv_smem(a.g, pro), ws = gemv_smem(a.w, PRO_PREQ);                                           \
+        if (gs > smem) smem = gs;                                                                                        \
+        if (ws > smem) smem = ws;                                                                                        \
+        if (smem > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(qkv_attn_wo_kernel<n_, l_, p_, hs_, nw_, lw_>)); \
+        LMRS_LAUNCH_GRID((qkv_attn_wo_kernel<n_, l_, p_, hs_, nw_, lw_>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a, n_qkv);        \
+        return hipGetLastError();                                                                                        \
+    }
+    LMRS_QAW_TABLE(X)
 #undef X
     return hipErrorNotSupported;
 }
@@ -1950,9 +2116,10 @@ __global__ __launch_bounds__(kBlock) void argmax_final_kernel(const ArgmaxArgs a
     float best = __uint_as_float(0xff800000u); int best_i = 0x7fffffff;
     int nan0 = 0;                                                  // index -1: the logit at index 0 is NaN (cls_flag_nan_at_zero)
     // partials: n_groups shards x n_part entries; shard g holds [values | indices] at part_val + g * group_stride
+    const size_t pofs = a.part_par ? (size_t)(*a.part_par & 1u) * a.part_par_floats : 0;        // the half the last exchange delivered
     for (int i = threadIdx.x; i < a.n_part * a.n_groups; i += kBlock) {
         const int g = i / a.n_part, k = i - g * a.n_part;
-        const float v = a.part_val[(size_t)g * a.group_stride + k]; const int idx = a.part_idx[(size_t)g * a.group_stride + k];
+        const float v = a.part_val[pofs + (size_t)g * a.group_stride + k]; const int idx = a.part_idx[pofs + (size_t)g * a.group_stride + k];
         if (idx < 0) { nan0 = 1; continue; }
         if (v > best || (v == best && idx < best_i)) { best = v; best_i = idx; }
     }
@@ -2228,12 +2395,14 @@ __global__ __launch_bounds__(kBlock) void exchange_push_kernel(const ExchangeArg
     __shared__ unsigned s_seq;
     const int tid = threadIdx.x;
     if (tid == 0) { s_seq = *a.my_seq + 1u; *a.my_seq = s_seq; }
+    __syncthreads();
+    const size_t pofs = (size_t)(s_seq & 1u) * (size_t)a.par_bytes;    // double-buffered block: this exchange's half
     if (a.qsrc) {                                          // my slice, quantised on its way out: [qn int8 | qn / 128 scales]
         int8_t* xq = reinterpret_cast<int8_t*>(smem);
         float* xs = reinterpret_cast<float*>(smem + ((a.qn + 15) & ~15));
         float4 v[kMaxP];
         load_vec(v, a.qsrc, a.qn);
-        char* blk = const_cast<char*>(a.local);
+        char* blk = const_cast<char*>(a.local) + pofs;
         quantize_to_lds<false, kMaxP>(v, a.qn, xq, xs, blk, reinterpret_cast<float*>(blk + a.qn));
         __threadfence();                                   // the block is re-read below by other lanes of this workgroup
     }
@@ -2241,7 +2410,7 @@ __global__ __launch_bounds__(kBlock) void exchange_push_kernel(const ExchangeArg
     for (int w = 0; w < a.world; ++w) {
         if (w == a.rank) continue;
         for (int off = tid * 16; off < a.bytes; off += kBlock * 16)
-            __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.local + off)), reinterpret_cast<i32x4*>(a.peer_dst[w] + off));
+            __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.local + pofs + off)), reinterpret_cast<i32x4*>(a.peer_dst[w] + pofs + off));
     }
     __threadfence_system();
     __syncthreads();

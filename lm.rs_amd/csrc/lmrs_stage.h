@@ -87,6 +87,10 @@ __device__ __forceinline__ void vec_load(float4 (&v)[(VecGeom<N, NTH>::NP)], con
 // scratch: rms_scratch_floats(N) floats of LDS.
 // `landed` runs right after the first barrier, i.e. once the activation has arrived (hook for deferred weight loads).
 constexpr int rms_scratch_floats(int n) { return 8 * (n / 8 + 8) + 4; }
+// (Round 4, measured and removed: the 8 chains from REGISTERS - chain k in row k & 3 of two waves, 16 squares per register, every add a
+// v_add_f32_dpp row_shr as in wave_serial_sum, no LDS read in the loop.  Bit-equal; the chain itself 0.83 -> 0.70 us in the qkv launch,
+// unchanged in w1/w3 (a DPP add issues every ~6 cycles, not 4), and the step 426 -> 441 us: two busy waves per workgroup instead of one
+// push out the slowest workgroup of every launch that has more workgroups than CUs.)
 // one 16-byte batch of the chain: this lane's four squares, then the four of the lane 8 above (row_shl:8: the DPP operand of the add
 // itself fetches them - see vec_rmsnorm)
 __device__ __forceinline__ void rms_chain8(float& p, const float4& a) {

@@ -699,14 +699,73 @@ def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan
         print(f"rank {r}: step graph captured = {graph}")
 
 
+def _p2p_stall_rank(rank, world, img_path, cfg, env, stall_us, q_in, q_out):
+    """One process of the stalled-peer test: plan "cls", steps enqueued eagerly; rank 1 spins on the device after every partials exchange."""
+    try:
+        import os, sys
+        os.environ.update(env)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+        import numpy as np
+        import lmrs_amd
+        from tools import synth_lmrs as S
+        img = np.fromfile(img_path, np.uint8)
+        m = lmrs_amd.Transformer(img, device=0, rank=rank, world=world)
+        q_out.put((rank, "handle", m.p2p_handle()))
+        m.p2p_connect(q_in.get(timeout=120))
+        m.debug_inject(1, 4 * m.args.n_layers, stall_us if rank == 1 else 0)     # eager steps on every rank; the stall on rank 1 only
+        toks = m.generate_greedy(S.prompt_tokens(cfg, 4, 46), 40)
+        q_out.put((rank, "done", toks))
+        m.close()
+    except Exception:
+        import traceback
+        q_out.put((rank, "error", traceback.format_exc()))
+
+
+def test_push_exchange_with_a_stalled_peer(L, tmp_path):
+    """Plan "cls" has ONE exchange per token (the argmax partials), so nothing but the exchange itself orders a shard that runs ahead
+    against a peer that has not yet consumed the previous block: rank 1 stalls 2 ms on the device between every partials exchange and
+    its argmax while rank 0 runs a whole step ahead and pushes the next partials.  The gathered partials are double-buffered by the
+    parity of the exchange (ArgmaxArgs::part_par), so rank 1 still reads step s while step s + 1 lands in the other half: token ids
+    identical to the CPU path on both ranks."""
+    import multiprocessing as mp
+    cfg, world = "mini-llama", 2
+    img = S.build_image(cfg, S.Q8_0, seed=47)
+    path = str(tmp_path / "m.lmrs"); img.tofile(path)
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue(); q_in = [ctx.Queue() for _ in range(world)]
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "LMRS_P2P_TIMEOUT_MS": "3000", "LMRS_SHARD_PLAN": "cls"}
+    procs = [ctx.Process(target=_p2p_stall_rank, args=(r, world, path, cfg, env, 2000, q_in[r], q_out)) for r in range(world)]
+    for p in procs: p.start()
+    try:
+        handles = {}
+        while len(handles) < world:
+            r, kind, val = q_out.get(timeout=90)
+            assert kind == "handle", val
+            handles[r] = val
+        for r in range(world): q_in[r].put([handles[i] for i in range(world)])
+        res = {}
+        while len(res) < world:
+            r, kind, val = q_out.get(timeout=120)
+            assert kind == "done", val
+            res[r] = val
+    finally:
+        for p in procs: p.join(30)
+        for p in procs:
+            if p.is_alive(): p.kill()
+    ref = O.Oracle(img).generate_greedy(S.prompt_tokens(cfg, 4, 46), 40)
+    for r in range(world):
+        assert (res[r] == ref).all(), (r, res[r], ref)
+
+
 def test_bench_fallback_is_taken_by_all_ranks_together(tmp_path):
     """The driver's multi-GPU launch (torch.distributed.run, one process per rank; here both ranks on ONE GPU over gloo) with a
-    peer-to-peer connect that fails on rank 1 only (LMRS_P2P_FAIL_RANK): rank 0, whose own connect succeeded, must drop its context
+    peer-to-peer connect that fails on rank 1 only (LMRS_BENCH_FAIL_RANK -> lmrs_debug_inject): rank 0, whose own connect succeeded, must drop its context
     too, both ranks must take the fallback branch together, and the run must complete with token parity.  (On one device the
     fallback is a second peer-to-peer attempt - RCCL refuses two ranks on one GPU; on a node it is the RCCL communicator.)"""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LMRS_BENCH_ONE_DEVICE="1", LMRS_P2P_FAIL_RANK="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, LMRS_BENCH_ONE_DEVICE="1", LMRS_BENCH_FAIL_RANK="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29597",
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--cpu-steps", "6"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
@@ -746,12 +805,20 @@ def test_merged_qkv_attention_launch_and_classifier_tail(L, monkeypatch, cfg, q)
     ref = orc.generate_greedy(prompt, n_new)
     m = L.Transformer(img)
     nl = m.args.n_layers
-    merged = m.step_info(0)[0] == 4 * nl + 1
-    assert merged, f"{cfg}: the merged launch is not in use ({m.step_info(0)[0]} launches per step)"
+    wo3 = (cfg, q) == ("mini-llama", S.Q8_0)                 # the shapes with a three-part class (LMRS_WO_MERGED=1, off by default: measured slower)
+    merged = m.step_info(0)[0] == 4 * nl + 1 and m.step_info(200)[0] == 4 * nl + 1
+    assert merged, f"{cfg}: the merged launch is not in use ({m.step_info(0)[0]} / {m.step_info(200)[0]} launches per step)"
     assert (m.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: default form"
     monkeypatch.setenv("LMRS_QKV_ATT", "1")                  # one workgroup per head from position 0
     m1 = L.Transformer(img)
+    assert m1.step_info(0)[0] == 4 * nl + 1
     assert (m1.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: workgroup form"
+    if wo3:
+        monkeypatch.setenv("LMRS_QKV_ATT", "2"); monkeypatch.setenv("LMRS_WO_MERGED", "1")
+        m2 = L.Transformer(img)
+        assert m2.step_info(0)[0] == 3 * nl + 1 and m2.step_info(200)[0] == 4 * nl + 1
+        assert (m2.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: wo inside the merged launch (three-part form)"
+        monkeypatch.delenv("LMRS_WO_MERGED")
     monkeypatch.setenv("LMRS_QKV_ATT", "0"); monkeypatch.setenv("LMRS_CLS_TAIL", "0")
     m0 = L.Transformer(img)
     assert m0.step_info(0)[0] == 5 * nl + 2

@@ -45,18 +45,3 @@ def test_bench_reads_the_profile_summaries_when_the_source_hash_matches():
     if rp["kernel_source_hash"] == h:
         assert r is not None and 300 < r < 700
     assert bench.pmc_traffic("llama-3.2-1b", "q4_0") is None or bench.pmc_traffic("llama-3.2-1b", "q4_0") > 0
-
-
-@pytest.mark.parametrize("patch", sorted(glob.glob(os.path.join(ROOT, "tools", "ubench", "*.patch"))))
-def test_ubench_patches_name_existing_files(patch):
-    """The patches under tools/ubench are work items kept as diffs: the next-round one must still apply to the tree; older
-    experiment records must at least point at files that exist."""
-    txt = open(patch).read()
-    targets = [ln[6:].split("\t")[0].strip() for ln in txt.splitlines() if ln.startswith("+++ b/")]
-    assert targets, patch
-    for t in targets:
-        assert os.path.exists(os.path.join(ROOT, t)), t
-    next_round = ("vis_attention_scalar_rows.patch", "qkv_attn_wo_three_part.patch")        # each against the committed tree on its own
-    if os.path.basename(patch) in next_round and os.path.isdir(os.path.join(ROOT, ".git")):
-        r = subprocess.run(["git", "apply", "--check", patch], cwd=ROOT, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr

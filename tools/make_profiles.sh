@@ -43,7 +43,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf -- p
 cp $(ls $OUT/pf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prefill512_kernel_stats.csv; rm -rf $OUT/pf
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vis -- python tools/vision_rate.py 2 24 > $OUT/${TAG}_vision_rate.log 2>&1
 cp $(ls $OUT/vis/*/*kernel_stats.csv | head -1) $OUT/${TAG}_vision_kernel_stats.csv; rm -rf $OUT/vis
-LMRS_BENCH_BOTH_PLANS=1 LMRS_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29581 bench.py --gpus 2 --steps 64 --warmup 16 --cpu-steps 8 2> $OUT/tp2.err | grep "^{" > $OUT/${TAG}_bench_two_ranks_one_device_both_plans.json
+LMRS_BENCH_ONE_DEVICE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29581 bench.py --gpus 2 --steps 64 --warmup 16 --cpu-steps 8 2> $OUT/tp2.err | grep "^{" > $OUT/${TAG}_bench_two_ranks_one_device_both_plans.json
 timeout 400 python bench.py --model phi-3.5 --steps 32 --vision > $OUT/${TAG}_bench_phi35_vision.json 2>> $OUT/bench.err
 for f in $OUT/${TAG}_bench*.json; do python - "$f" <<'PY'
 import json, sys

@@ -348,9 +348,11 @@ def main():
                 "bound": "hbm", "kernel": "lmrs::gemv_static_kernel / gemv_kernel / qkv_attn_kernel (fused dequant-GEMV, all shapes of one step; the qkv launch includes the attention workgroups merged into it, the classifier the folded argmax), durations taken inside the real step",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "frac_vs_measured_copy": round(achieved / MEASURED_COPY_GBPS, 4),
-                # the same bytes over rocprofv3's average durations of the same kernels (committed summary of this build, else null): the
-                # profiler's per-dispatch intervals overlap at the launch boundaries and run a few percent above the event intervals
+                # the same bytes over rocprofv3's average durations of the same kernels (committed summary of this build, else null).  A LOWER
+                # BOUND, not a second measurement of kernel time: under graph replay the profiler's per-dispatch intervals include each launch's
+                # boundary and overlap their neighbours' - their sum exceeds the timed step itself (round 3: 471 us of "kernels" in a 424 us step)
                 "frac_rocprof": round(tot_b / rp_us / 1e3 / HBM_PEAK_GBPS, 4) if rp_us else None,
+                "frac_rocprof_is": "lower bound (profiler intervals overlap at launch boundaries; see path.frac for the timed step)",
                 "traffic": pmc_traffic(cfg.name, args.qtype),
                 "bytes_per_launch_avg": round(tot_b / n_gemv), "avg_launch_us": round(tot_us / n_gemv, 3), "launches_per_step": n_gemv,
                 "in_step": per, "sum_of_kernel_us_per_step": round(step_us, 2), "kernel_source_hash": kernel_source_hash(),

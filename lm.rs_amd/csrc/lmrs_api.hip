@@ -98,6 +98,7 @@ struct lmrs_ctx {
     // a shard pushes its block straight into its peers' copies (xGMI stores) and raises a flag there (exchange_push_kernel)
     bool p2p = false, p2p_ready = false; char* xarena = nullptr; size_t xarena_bytes = 0; char* peer_base[kMaxWorld] = {};
     unsigned *xflags = nullptr, *xseq = nullptr; int* xerr = nullptr; int ex_slot = 0; bool xarena_is_ipc[kMaxWorld] = {};
+    bool err_queued = false;                       // the error word's copy to h_err rides in front of the call's own synchronise (queue_err)
     int* err = nullptr; int* h_err = nullptr;      // error word of the bounded in-launch waits (merged qkv + attention launch, classifier tail)
     // ---- merged qkv + attention launch (launch_qkv_attn): per-layer {value, tag} granules, the step sequence number the tags are
     // made of (bumped by the last kernel of every step, never reset), and the graph of the separate kernels for the steps it does not cover
@@ -633,6 +634,14 @@ int set_state(lmrs_ctx* c, uint32_t pos, uint32_t prompt_end, int win_base = -1)
 }
 
 // after a host sync: did a bounded in-launch wait give up?
+// the in-launch waits' error word -> pinned host memory, queued on the stream BEFORE the synchronise every call ends with: the check then
+// costs no round trip of its own (a blocking 4-byte copy per token was ~10 us on a path trimmed by microseconds)
+int queue_err(lmrs_ctx* c) {
+    if (!c->err || !(c->qkv_att || c->cls_tail)) return 0;
+    HIP_OK(hipMemcpyAsync(c->h_err, c->err, 4, hipMemcpyDeviceToHost, c->stream));
+    c->err_queued = true;
+    return 0;
+}
 int check_err(lmrs_ctx* c) {
     if (c->xerr) {
         int e = 0;
@@ -640,7 +649,8 @@ int check_err(lmrs_ctx* c) {
         if (e) { (void)hipMemset(c->xerr, 0, 4); return fail("peer-to-peer exchange " + std::to_string(e - 1) + " timed out waiting for a peer (results of this call are invalid)"); }
     }
     if (!c->err || !(c->qkv_att || c->cls_tail)) return 0;
-    HIP_OK(hipMemcpy(c->h_err, c->err, 4, hipMemcpyDeviceToHost));
+    if (c->err_queued) c->err_queued = false;                   // already copied by the stream, ahead of the synchronise the caller just did
+    else HIP_OK(hipMemcpy(c->h_err, c->err, 4, hipMemcpyDeviceToHost));
     if (*c->h_err) return fail("in-launch synchronisation timed out at stage " + std::to_string(*c->h_err - 1) + " (results of this call are invalid)");
     return 0;
 }
@@ -1193,6 +1203,7 @@ extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** l
         if (rc) return -1;
     }
     HIP_OK(hipMemcpyAsync(c->h_logits, c->logits, (size_t)c->args.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
+    if (queue_err(c)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
     if (logits) *logits = c->h_logits;
@@ -1202,6 +1213,7 @@ extern "C" int lmrs_forward(lmrs_ctx* c, uint32_t token, uint32_t pos, float** l
 extern "C" int lmrs_forward_argmax(lmrs_ctx* c, uint32_t token, uint32_t pos, uint32_t* next) {
     if (step_once(c, token, pos)) return -1;
     HIP_OK(hipMemcpyAsync(c->h_tok + 1, c->tokens + pos + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    if (queue_err(c)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
     if (next) *next = c->h_tok[1];
@@ -1226,6 +1238,7 @@ extern "C" int lmrs_forward_sample(lmrs_ctx* c, uint32_t token, uint32_t pos, lm
     SampleArgs sa{c->logits, (int)c->args.vocab_size, temp, rnd, c->part_val, c->part_val + kSampleGrid + 1, c->tokens + c->args.seq_len + 4};   // (scratch: the argmax partials; a spare token slot)
     HIP_OK(launch_sample_mult(sa, c->stream));
     HIP_OK(hipMemcpyAsync(c->h_tok + 1, sa.out_token, 4, hipMemcpyDeviceToHost, c->stream));
+    if (queue_err(c)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
     *next = c->h_tok[1];
@@ -1367,6 +1380,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
             HIP_OK(hipMemcpyAsync(embeddings + (size_t)i * dim, c->x, dim * 4, hipMemcpyDeviceToHost, c->stream));
         }
         c->att_split_chunks = chunks0;
+        if (queue_err(c)) return -1;
         HIP_OK(hipStreamSynchronize(c->stream));
         if (check_err(c)) return -1;
         if (new_pos) *new_pos = curr_pos + n;
@@ -1385,6 +1399,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
             HIP_OK(hipMemcpyAsync(embeddings + (size_t)i0 * dim, c->pf_x, (size_t)m * dim * 4, hipMemcpyDeviceToHost, c->stream));
         }
         if (set_state(c, curr_pos + n, 0)) return -1;
+        if (queue_err(c)) return -1;
         HIP_OK(hipStreamSynchronize(c->stream));
         if (check_err(c)) return -1;
         if (new_pos) *new_pos = curr_pos + n;
@@ -1399,6 +1414,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
         HIP_OK(hipGraphLaunch(c->g_layers, c->stream));
         HIP_OK(hipMemcpyAsync(embeddings + (size_t)i * dim, c->x, dim * 4, hipMemcpyDeviceToHost, c->stream));
     }
+    if (queue_err(c)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
     if (new_pos) *new_pos = curr_pos + n;
@@ -1473,6 +1489,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     }
     HIP_OK(hipEventRecord(c->ev1, c->stream));
     if (n_new) HIP_OK(hipMemcpyAsync(c->h_tok, c->tokens + start_pos + n_prompt, (size_t)n_new * 4, hipMemcpyDeviceToHost, c->stream));
+    if (queue_err(c)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
     if (n_new) memcpy(out_tokens, c->h_tok, (size_t)n_new * 4);

@@ -275,6 +275,35 @@ __device__ __forceinline__ void argmax_tail(const ArgmaxArgs& a, float best, int
                 *reinterpret_cast<float4*>(a.emb.x + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
             }
         }
+    } else if (a.emb.q4 == 1 && a.emb.dim > 0 && (a.emb.dim & 7) == 0 && a.emb.dim <= 8 * 4 * kBlock) {
+        // Q4_0 rows the same way: 8 elements = 4 packed bytes per thread and pass, every load of the row in flight before the first use
+        // (even element = low nibble; value = (nibble - 8) * scale, quantization.rs:25-42)
+        const uint8_t* qrow = reinterpret_cast<const uint8_t*>(a.emb.emb_q) + ((size_t)token * a.emb.dim) / 2;
+        const float* srow = a.emb.emb_s + ((size_t)token * a.emb.dim) / kGS;
+        unsigned q4w[4]; float sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (k * kBlock + (int)threadIdx.x) * 8;
+            const bool live = e < a.emb.dim;
+            q4w[k] = *reinterpret_cast<const unsigned*>(qrow + (live ? e : 0) / 2);
+            sc[k] = srow[(live ? e : 0) / kGS];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = (k * kBlock + (int)threadIdx.x) * 8;
+            if (e < a.emb.dim) {
+                float o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int nib = (int)((q4w[k] >> (4 * u)) & 0xfu) - 8;
+                    float v = (float)nib * sc[k];
+                    if (a.emb.do_scale) v = v * a.emb.scale;
+                    o[u] = v;
+                }
+                *reinterpret_cast<float4*>(a.emb.x + e) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(a.emb.x + e + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
     } else {
         for (int i = threadIdx.x; i < a.emb.dim; i += kBlock) {
             float v = dequant_elem(a.emb.emb_q, a.emb.emb_s, a.emb.q4, (size_t)token * a.emb.dim + i);
@@ -718,6 +747,9 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     } else {
         unsigned long long* dbg = bid == 0 ? a.dbg : nullptr;
         if constexpr (PRO == PRO_ADD_RMS_QUANT) {
+            // (Round 4, measured and removed: requesting the second pass's tile from inside this ~5 us prologue, once the branch output has
+            // landed.  Gemma-2-2B Q4_0: 889 -> 894 us per step with three passes per workgroup, 898 -> 952 with two - the tiles of 288
+            // workgroups queued ahead of each other's norm-weight and residual loads.)
             vec_rmsnorm<N, NTH>(dl, aw, a.eps, a.add_unit, scratch);                 // rmsnorm(branch output)
 #pragma unroll
             for (int i = 0; i < V::NP; ++i) {
@@ -1052,7 +1084,15 @@ int gemv_grid(const GemvArgs& a, int pro, int epi) {
     const int n_pass = (a.o + RB - 1) / RB;
     int cap = 4096;
     if (epi == EPI_CLS) cap = 512;                         // classifier: persistent-style grid, prologue paid once per workgroup
-    else if (sc.L && (epi == EPI_SWIGLU || epi == EPI_GELU)) cap = (n_pass + 1) / 2;   // w1w3: two passes per workgroup
+    else if (sc.L && (epi == EPI_SWIGLU || epi == EPI_GELU)) {                             // w1w3: two passes per workgroup ...
+        static const int forced = env_flag("LMRS_GLU_PASSES", 0);
+        int k = 2;
+        // ... unless that leaves a grid between one and two workgroups per CU (Gemma-2-2B: 288 on 256 CUs - 32 CUs then carry twice the
+        // stream and two prologues, and the launch ends with them): three passes per workgroup when that fits one per CU
+        if (n_pass / 2 > 256 && n_pass / 2 < 448 && (n_pass + 2) / 3 <= 256) k = 3;
+        if (forced > 0) k = forced;
+        cap = (n_pass + k - 1) / k;
+    }
     return n_pass < cap ? n_pass : cap;
 }
 

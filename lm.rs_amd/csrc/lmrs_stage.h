@@ -1,5 +1,5 @@
 // lmrs_stage.h — fully static (compile-time shape) building blocks of the decode path, shared by the
-// per-stage kernels (lmrs_kernels.hip), the batched prefill (lmrs_prefill.inc) and the fused attention block (lmrs_fused.inc).
+// per-stage kernels (lmrs_kernels.hip), the merged qkv + attention launch and the batched prefill (lmrs_prefill.inc).
 //
 // Why static: with the vector length N, the lanes-per-row L and the steps-per-lane U known at compile
 // time there is not a single data-dependent branch around a global load, so hipcc keeps *counted*

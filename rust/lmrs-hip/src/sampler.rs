@@ -9,6 +9,7 @@ use crate::transformer::Transformer;
 
 pub struct Sampler {
     pub(crate) handle: *mut LmrsSampler,
+    vocab_size: u32,
 }
 
 impl Sampler {
@@ -16,11 +17,13 @@ impl Sampler {
     pub fn new(vocab_size: u32, temperature: f32, top_p: f32, seed: u64) -> Sampler {
         let mut handle: *mut LmrsSampler = ptr::null_mut();
         check(unsafe { ffi::lmrs_sampler_create(vocab_size, temperature, top_p, seed, &mut handle) });
-        Sampler { handle }
+        Sampler { handle, vocab_size }
     }
 
     /// sampler.rs:109 - `logits` is scaled and softmax-ed in place exactly as the reference mutates its argument.
     pub fn sample(&mut self, logits: &mut [f32]) -> u32 {
+        // the C side reads and writes vocab_size floats: a shorter slice must fail here, as the reference's indexing would (sampler.rs:114)
+        assert!(logits.len() >= self.vocab_size as usize, "logits shorter than the sampler's vocabulary");
         let mut next: u32 = 0;
         check(unsafe { ffi::lmrs_sampler_sample(self.handle, logits.as_mut_ptr(), &mut next) });
         next

@@ -309,7 +309,9 @@ def test_matmul_q8_token_batch_on_matrix_cores(L, n, o, sl):
 
 @pytest.mark.parametrize("cfg,q,n_tok,pos0", [("mini-llama", S.Q8_0, 70, 5), ("mini-llama3b", S.Q8_0, 33, 0), ("mini-phi", S.Q8_0, 140, 2),
                                               ("mini-llama-long", S.Q8_0, 600, 3), ("mini-llama", S.Q4_0, 70, 5), ("mini-gemma", S.Q8_0, 50, 3),
-                                              ("mini-gemma", S.Q4_0, 75, 0)])
+                                              ("mini-gemma", S.Q4_0, 75, 0),
+                                              # 48 <= tokens < 64: the LDS-DMA ring GEMM's smallest batches (one ragged token tile)
+                                              ("mini-llama", S.Q8_0, 48, 1), ("mini-llama3b", S.Q8_0, 57, 0), ("mini-phi", S.Q8_0, 63, 2)])
 def test_fill_kv_cache_batched_prefill(L, cfg, q, n_tok, pos0):
     """forward_layer(sl = n) as GEMMs over the token batch (more than one 64-token block; 600 tokens: more than one 512-token chunk):
     the mutated embeddings, and the decode steps that continue on the prefilled KV cache, are bit-identical to the CPU path.

@@ -270,12 +270,18 @@ typedef struct lmrs_sampler lmrs_sampler;
 int lmrs_sampler_create(uint32_t vocab_size, float temperature, float top_p, uint64_t seed, lmrs_sampler** out);
 void lmrs_sampler_destroy(lmrs_sampler* s);
 int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
+/* sample_topp (sampler.rs:67-106) from its sort on, for a caller that ran the temperature scaling, the softmax and the cutoff filter
+ * elsewhere (lmrs_forward_sample runs them on the device): pairs = n0 candidates {f32 prob, u32 index} with
+ * prob >= (1 - top_p) / (vocab_size - 1), in index order - what :74-80 leaves in probindex[0 .. n0). */
+int lmrs_sampler_topp_pairs(lmrs_sampler* s, const void* pairs, size_t n0, uint32_t* next);
 int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd);   /* rnd = random_f32(seed), the same on every call (:119) */
 /* Transformer::forward (src/transformer.rs:316) followed by Sampler::sample (src/sampler.rs:109-129) with the logits staying in HBM:
  * temperature 0 -> the argmax fused into the decode step; temperature != 0 with top_p outside (0, 1) -> temperature scaling, softmax in
  * place and sample_mult ON THE DEVICE (sample_*_kernel: the reference's sequential sums run lane by lane in one wave); top_p inside (0, 1)
- * (sample_topp: a stable sort of the sampler's persistent candidate vector, :67-106) -> lmrs_forward + lmrs_sampler_sample on the host.
- * Same token as lmrs_forward + lmrs_sampler_sample in every case.  One-GPU contexts. */
+ * (sample_topp, :67-106 - the reference's default, chat.rs:28-31) -> scaling, softmax and the cutoff filter on the device, only the
+ * surviving (prob, index) pairs cross to the host, where lmrs_sampler_topp_pairs runs the stable sort over the sampler's persistent
+ * candidate vector, the cumulative cut and the draw (when more than half the vocabulary survives - a nearly flat distribution - the
+ * probabilities are copied instead).  Same token as lmrs_forward + lmrs_sampler_sample in every case.  One-GPU contexts. */
 int lmrs_forward_sample(lmrs_ctx* ctx, uint32_t token, uint32_t pos, lmrs_sampler* sampler, uint32_t* next);
 
 #ifdef __cplusplus

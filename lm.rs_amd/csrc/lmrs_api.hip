@@ -98,6 +98,7 @@ struct lmrs_ctx {
     // a shard pushes its block straight into its peers' copies (xGMI stores) and raises a flag there (exchange_push_kernel)
     bool p2p = false, p2p_ready = false; char* xarena = nullptr; size_t xarena_bytes = 0; char* peer_base[kMaxWorld] = {};
     unsigned *xflags = nullptr, *xseq = nullptr; int* xerr = nullptr; int ex_slot = 0; bool xarena_is_ipc[kMaxWorld] = {};
+    void* topp_pairs = nullptr;                    // lmrs_forward_sample, top-p: vocab_size (prob, index) pairs + the filter's counts (allocated on first use)
     bool err_queued = false;                       // the error word's copy to h_err rides in front of the call's own synchronise (queue_err)
     int* err = nullptr; int* h_err = nullptr;      // error word of the bounded in-launch waits (merged qkv + attention launch, classifier tail)
     // ---- merged qkv + attention launch (launch_qkv_attn): per-layer {value, tag} granules, the step sequence number the tags are
@@ -1115,6 +1116,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->g_step) (void)hipGraphExecDestroy(c->g_step);
     for (auto& g : c->g_step_long) if (g) (void)hipGraphExecDestroy(g);
     if (c->att_S) (void)hipFree(c->att_S);
+    if (c->topp_pairs) (void)hipFree(c->topp_pairs);
     if (c->g_layers) (void)hipGraphExecDestroy(c->g_layers);
     for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : c->g_multi) if (g) (void)hipGraphExecDestroy(g);
@@ -1223,16 +1225,49 @@ extern "C" int lmrs_forward_argmax(lmrs_ctx* c, uint32_t token, uint32_t pos, ui
 struct lmrs_sampler;
 extern "C" int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd);
 extern "C" int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
+extern "C" int lmrs_sampler_topp_pairs(lmrs_sampler* s, const void* pairs, size_t n0, uint32_t* next);
 extern "C" int lmrs_forward_sample(lmrs_ctx* c, uint32_t token, uint32_t pos, lmrs_sampler* sampler, uint32_t* next) {
     if (!c || !sampler || !next) return fail("NULL argument");
     uint32_t vs = 0; float temp = 0, top_p = 0, rnd = 0;
     if (lmrs_sampler_info(sampler, &vs, &temp, &top_p, &rnd)) return -1;
     if (vs != c->args.vocab_size) return fail("the sampler was made for another vocabulary size");
     if (temp == 0.0f) return lmrs_forward_argmax(c, token, pos, next);                    // sample_argmax: fused into the step
-    if ((top_p > 0.0f && top_p < 1.0f) || c->world > 1 || c->comm) {                       // sample_topp / sharded logits: the host sampler
+    if (c->world > 1 || c->comm) {                                                        // sharded logits: the host sampler
         float* lg = nullptr;
         if (lmrs_forward(c, token, pos, &lg)) return -1;
         return lmrs_sampler_sample(sampler, lg, next);
+    }
+    if (top_p > 0.0f && top_p < 1.0f) {
+        // sample_topp (sampler.rs:67-106): scaling, softmax and the cutoff filter on the device; the candidates - a handful for a peaked
+        // distribution - go to the host as (prob, index) pairs in index order, the sort over the sampler's persistent vector runs there
+        const size_t n = c->args.vocab_size;
+        if (!c->topp_pairs) HIP_OK(hipMalloc(&c->topp_pairs, n * 8 + 256 * 4 + 16));
+        unsigned* counts = reinterpret_cast<unsigned*>(static_cast<char*>(c->topp_pairs) + n * 8);
+        unsigned* n0d = counts + 256;
+        if (step_once(c, token, pos)) return -1;
+        SampleArgs sa{c->logits, (int)n, temp, rnd, c->part_val, c->part_val + kSampleGrid + 1, c->tokens + c->args.seq_len + 4};
+        const float cutoff = (1.0f - top_p) / (float)(n - 1);                             // :71, f32 as in the reference
+        HIP_OK(launch_sample_topp_filter(sa, cutoff, c->topp_pairs, n0d, counts, c->stream));
+        // one transfer for the usual case: the count and the first kToppEager pairs land together in the pinned logits buffer
+        constexpr size_t kToppEager = 2048;
+        const size_t eager = std::min(kToppEager, n / 2);                                 // (the pinned buffer holds vocab_size floats = vocab_size / 2 pairs)
+        uint32_t* hn0 = c->h_tok + 2;
+        HIP_OK(hipMemcpyAsync(hn0, n0d, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipMemcpyAsync(c->h_logits, c->topp_pairs, eager * 8, hipMemcpyDeviceToHost, c->stream));
+        if (queue_err(c)) return -1;
+        HIP_OK(hipStreamSynchronize(c->stream));
+        if (check_err(c)) return -1;
+        const size_t n0 = *hn0;
+        if (n0 > n / 2) {                                  // nearly flat: the probability vector is the smaller message (and h_logits holds exactly that)
+            HIP_OK(hipMemcpy(c->h_logits, c->logits, n * 4, hipMemcpyDeviceToHost));
+            std::vector<float> pairs(2 * n0);
+            size_t k = 0;
+            for (size_t i = 0; i < n && k < n0; ++i)
+                if (c->h_logits[i] >= cutoff) { pairs[2 * k] = c->h_logits[i]; uint32_t ix = (uint32_t)i; memcpy(&pairs[2 * k + 1], &ix, 4); ++k; }
+            return lmrs_sampler_topp_pairs(sampler, pairs.data(), k, next);
+        }
+        if (n0 > eager) HIP_OK(hipMemcpy(reinterpret_cast<char*>(c->h_logits) + eager * 8, static_cast<char*>(c->topp_pairs) + eager * 8, (n0 - eager) * 8, hipMemcpyDeviceToHost));
+        return lmrs_sampler_topp_pairs(sampler, c->h_logits, n0, next);
     }
     if (step_once(c, token, pos)) return -1;
     SampleArgs sa{c->logits, (int)c->args.vocab_size, temp, rnd, c->part_val, c->part_val + kSampleGrid + 1, c->tokens + c->args.seq_len + 4};   // (scratch: the argmax partials; a spare token slot)

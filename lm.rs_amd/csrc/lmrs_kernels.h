@@ -144,6 +144,9 @@ hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint
 struct SampleArgs { float* logits; int n; float temperature; float rnd; float* part; float* sum; uint32_t* out_token; };
 constexpr int kSampleGrid = 256;
 hipError_t launch_sample_mult(const SampleArgs& a, hipStream_t s);
+// ... and sample_topp's front half (sampler.rs:67-80): temperature scaling, softmax, then the candidates p >= cutoff as (prob, index)
+// pairs in index order -> pairs[0 .. *n0) (room for a.n pairs); counts: kSampleGrid unsigned of scratch.  a.rnd / a.out_token unused.
+hipError_t launch_sample_topp_filter(const SampleArgs& a, float cutoff, void* pairs, unsigned* n0, unsigned* counts, hipStream_t s);
 
 // thin kernels over the same device functions, for the lmrs_op_* unit-parity entry points
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st);

@@ -2257,6 +2257,63 @@ __global__ __launch_bounds__(64) void sample_pick_kernel(const SampleArgs a) {
     }
     if (lane == 0) *a.out_token = pick;
 }
+// sample_topp's filter (sampler.rs:74-80) on the device: the candidates `p >= cutoff` leave as (prob, index) pairs IN INDEX ORDER - the
+// order the reference's loop appends them in, which its stable sort preserves among equal probabilities - so that only they cross to
+// the host, not 513 KB of probabilities.  Two launches over contiguous chunks: counts per workgroup, then every workgroup's offset
+// (the counts before it) + an order-preserving scan of its own chunk.
+__global__ __launch_bounds__(kBlock) void topp_count_kernel(const float* __restrict__ p, int n, float cutoff, int chunk, unsigned* __restrict__ counts) {
+    __shared__ unsigned red[kBlock / 64];
+    const int i0 = blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    unsigned c = 0;
+    for (int i = i0 + threadIdx.x; i < i1; i += kBlock) c += p[i] >= cutoff ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor((int)c, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+struct ToppPair { float prob; uint32_t index; };             // = lmrs_sampler::ProbIndex (lmrs_text.cpp)
+__global__ __launch_bounds__(kBlock) void topp_compact_kernel(const float* __restrict__ p, int n, float cutoff, int chunk, const unsigned* __restrict__ counts,
+                                                              ToppPair* __restrict__ out, unsigned* __restrict__ n0) {
+    __shared__ unsigned red[kBlock / 64], wsum[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // candidates in the chunks before this one (gridDim.x <= kBlock counts)
+    unsigned before = (int)threadIdx.x < (int)blockIdx.x ? counts[threadIdx.x] : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor((int)before, off);
+    if (lane == 0) red[wave] = before;
+    __syncthreads();
+    unsigned base = red[0] + red[1] + red[2] + red[3];
+    const int i0 = blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    for (int j0 = i0; j0 < i1; j0 += kBlock) {                // kBlock consecutive elements per round, one per thread: index order
+        const int i = j0 + (int)threadIdx.x;
+        const float v = i < i1 ? p[i] : 0.0f;
+        const bool keep = i < i1 && v >= cutoff;
+        const unsigned long long m = __ballot(keep);
+        const unsigned below = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();                                      // (wsum of the previous round has been read)
+        if (lane == 0) wsum[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) wbase += wsum[w]; total += wsum[w]; }
+        if (keep) out[base + wbase + below] = ToppPair{v, (uint32_t)i};
+        base += total;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n0 = base;
+}
+hipError_t launch_sample_topp_filter(const SampleArgs& a, float cutoff, void* pairs, unsigned* n0, unsigned* counts, hipStream_t s) {
+    if (a.n <= 0 || !a.logits || !a.part || !a.sum || !pairs || !n0 || !counts) return hipErrorInvalidValue;
+    LMRS_LAUNCH_GRID(sample_scale_max_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
+    LMRS_LAUNCH_GRID(sample_exp_kernel, dim3(kSampleGrid), kBlock, 0, s, a, (int)kSampleGrid);
+    LMRS_LAUNCH_GRID(sample_sum_kernel, dim3(1), 64, 0, s, a);
+    LMRS_LAUNCH_GRID(sample_div_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
+    const int chunk = (a.n + kSampleGrid - 1) / kSampleGrid;
+    LMRS_LAUNCH_GRID(topp_count_kernel, dim3(kSampleGrid), kBlock, 0, s, (const float*)a.logits, a.n, cutoff, chunk, counts);
+    LMRS_LAUNCH_GRID(topp_compact_kernel, dim3(kSampleGrid), kBlock, 0, s, (const float*)a.logits, a.n, cutoff, chunk, (const unsigned*)counts, static_cast<ToppPair*>(pairs), n0);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample_mult(const SampleArgs& a, hipStream_t s) {
     if (a.n <= 0 || !a.logits || !a.part || !a.sum || !a.out_token) return hipErrorInvalidValue;
     LMRS_LAUNCH_GRID(sample_scale_max_kernel, dim3(kSampleGrid), kBlock, 0, s, a);

@@ -304,6 +304,17 @@ template <int N, int L, int NTH = kBlk, bool Q4 = false> struct RowGeom {
     static constexpr int WR = Q4 ? L - 8 : L - CL;                // first lane of the row that holds the finished sum
 };
 
+// The running sum of a row's cluster j - 1 (8 lanes, every lane holds it) for cluster j, without an LDS round trip: inside a 16-lane
+// row the lane 8 below (row_shr:8); across rows lane 15 of the row below (row_bcast:15), from row 1 to row 2 lane 31 (row_bcast:31).
+// j = index of the RECEIVING cluster inside its row of L lanes (1 .. L/8 - 1).  ds_bpermute (__shfl) cost ~100 cycles per hop on the
+// critical path of every row: 7 hops for the 64-lane rows of w2.
+template <int L> __device__ __forceinline__ float cluster_carry(float acc, const int j) {      // j: a constant after unrolling - the branches fold
+    const int first = j * 8;                                      // first lane (within the row of L) of the receiving cluster
+    if (first % 16 == 8) return dpp_f<0x118>(acc);                // row_shr:8
+    if (L == 64 && first == 32) return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x143, 0xF, 0xF, false));   // row_bcast:31 (rows 0,1 -> 2,3)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x142, 0xF, 0xF, false));                            // row_bcast:15 (lane 15 of the row below)
+}
+
 template <int U> struct WTile { i32x4 w[U]; float sc[U]; };
 
 // steps [U0, U1) of the tile (the whole tile by default)
@@ -396,7 +407,12 @@ __device__ __forceinline__ float tile_consume(const WTile<RowGeom<N, L, kBlk, Q4
     } else {
 #pragma unroll
         for (int j = 0; j < R::NC; ++j) {
-            const float carry = j == 0 ? 0.0f : __shfl(acc, (lane & ~(L - 1)) + (j - 1) * R::CL);
+            float carry = 0.0f;
+#ifdef LMRS_SHFL_CARRY                                               // (A/B build: the ds_bpermute hops of rounds 1-3)
+            if (j > 0) carry = __shfl(acc, (lane & ~(L - 1)) + (j - 1) * R::CL);
+#else
+            if (j > 0) carry = cluster_carry<L>(acc, j);
+#endif
             if (cl == j) {
                 acc = carry;
 #pragma unroll

@@ -72,18 +72,34 @@ def test_sampler_on_the_device(L, n, temperature):
 
 
 def test_forward_sample_matches_forward_plus_host_sampler(L):
-    """lmrs_forward_sample (logits stay in HBM) against lmrs_forward + lmrs_sampler_sample: greedy, temperature sampling, top-p."""
+    """lmrs_forward_sample (logits stay in HBM) against lmrs_forward + lmrs_sampler_sample: greedy, temperature sampling, top-p
+    (scaling, softmax and the cutoff filter on the device, the candidates' sort on the host)."""
     img = S.build_image("mini-llama", S.Q8_0, seed=77)
     prompt = S.prompt_tokens("mini-llama", 4, 77)
-    for temperature, top_p in [(0.0, 0.9), (0.8, 1.0), (1.5, 0.0), (0.7, 0.9)]:
+    for temperature, top_p, steps in [(0.0, 0.9, 12), (0.8, 1.0, 12), (1.5, 0.0, 12), (0.7, 0.9, 200), (0.05, 0.5, 60), (3.0, 0.999, 40)]:
         a = L.Transformer(img); b = L.Transformer(img)
         sa = L.Sampler(a.args.vocab_size, temperature, top_p, 12345); sb = L.Sampler(b.args.vocab_size, temperature, top_p, 12345)
         ta = tb = None
-        for pos in range(12):
+        for pos in range(steps):
             t = int(prompt[pos]) if pos < len(prompt) else ta
             ta = a.forward_sample(t, pos, sa)
             tb = sb.sample(b.forward(t, pos))
             assert ta == tb, f"temperature {temperature}, top_p {top_p}, pos {pos}: device {ta}, host {tb}"
+
+
+def test_topp_filter_on_peaked_and_flat_distributions(L):
+    """sample_topp's device front half on the real vocabulary size: a peaked distribution (a handful of candidates cross to the host), a flat
+    one (more than half the vocabulary passes the cutoff: the probabilities are copied instead) and stale candidates of an earlier, wider
+    call still in the sampler's persistent vector - each against the host sampler on the same logits, through the classifier-less op path."""
+    rng = np.random.default_rng(5)
+    img = S.build_image("mini-llama", S.Q8_0, seed=78)
+    a = L.Transformer(img); b = L.Transformer(img)
+    V = a.args.vocab_size
+    for temperature, top_p in [(0.7, 0.9), (1.0, 0.3)]:
+        sa = L.Sampler(V, temperature, top_p, 777); sb = L.Sampler(V, temperature, top_p, 777)
+        for pos in range(30):                                  # one pair of samplers across calls: the persistent-vector quirk is exercised
+            t = int(rng.integers(0, V))
+            assert a.forward_sample(t, pos, sa) == sb.sample(b.forward(t, pos)), (temperature, top_p, pos)
 
 
 @pytest.mark.parametrize("c", [1.0, 0.7978845608028654])

@@ -122,6 +122,23 @@ def test_sampler_matches_the_second_transcription(L, temperature, top_p, seed):
         assert (a.view(np.uint32) == np.array(b, np.float32).view(np.uint32)).all(), f"call {call}: logits after sample() differ"
 
 
+def test_topp_from_candidate_pairs_equals_the_whole_sampler(L):
+    """lmrs_sampler_topp_pairs (what lmrs_forward_sample hands the host after the device has scaled, soft-maxed and filtered) against
+    lmrs_sampler_sample on the same logits, one persistent sampler each over many calls: narrow calls after wide ones leave stale
+    candidates in the vector the reference sorts as a whole (sampler.rs:81)."""
+    rng = np.random.default_rng(11)
+    V = 3000
+    a = L.Sampler(V, 0.7, 0.9, 4242); b = L.Sampler(V, 0.7, 0.9, 4242)
+    cutoff = np.float32((np.float32(1.0) - np.float32(0.9)) / np.float32(V - 1))
+    for call in range(40):
+        spread = [0.5, 8.0, 30.0][call % 3]                    # flat, peaked, very peaked
+        logits = (rng.standard_normal(V) * spread).astype(np.float32)
+        probs = logits.copy()
+        want = a.sample(probs)                                 # probs now holds the probabilities (scaled and soft-maxed in place, sampler.rs:115-117)
+        keep = np.flatnonzero(probs >= cutoff).astype(np.uint32)
+        assert b.topp_pairs(probs[keep], keep) == want, call
+
+
 def test_sampler_argmax_rule(L):
     s = L.Sampler(6, 0.0, 0.9, 1)
     assert s.sample(np.array([1, 5, 5, 2, 5, 0], np.float32)) == 1                      # first index of the maximum

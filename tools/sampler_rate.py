@@ -15,7 +15,10 @@ model = sys.argv[1] if len(sys.argv) > 1 else "llama-3.2-1b"
 img = S.build_image(model, S.Q8_0, 1234)
 m = lmrs_amd.Transformer(img)
 prompt = S.prompt_tokens(model, 8, 1234)
-for t, top_p, name in [(0.0, 0.9, "greedy (argmax fused into the step)"), (0.8, 1.0, "temperature 0.8, sample_mult")]:
+cases = [(0.0, 0.9, "greedy (argmax fused into the step)"), (0.8, 1.0, "temperature 0.8, sample_mult"),
+         (0.7, 0.9, "temperature 0.7, top-p 0.9 (the reference's defaults; synthetic weights: a nearly flat distribution, most of the vocabulary passes the cutoff)"),
+         (0.02, 0.9, "temperature 0.02, top-p 0.9 (a peaked distribution, as a trained model's: a handful of candidates)")]
+for t, top_p, name in cases:
     s = lmrs_amd.Sampler(m.args.vocab_size, t, top_p, 99)
     for pos, tk in enumerate(prompt):
         m.forward_argmax(int(tk), pos)

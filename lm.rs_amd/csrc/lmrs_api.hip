@@ -118,6 +118,8 @@ struct lmrs_ctx {
     bool aql_on = false; int aql_fence = 1; AqlProgram* aql_prog[3] = {nullptr, nullptr, nullptr};
     // three-part launch (launch_qkv_attn_wo, wave form only): per-layer granules of the quantised attention output
     bool wo_merged = false; unsigned long long* qgran = nullptr;
+    // wo + w1/w3 as one launch (launch_wo_w13, round-4 prototype, LMRS_WO_W13=1): per-layer granules of the residual stream
+    bool wo13 = false; unsigned long long* xgran = nullptr;
 
     template <class T> T* alloc(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -265,6 +267,17 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     else HIP_OK(launch_attention(t, c->stream));
     }
     g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
+    if (c->wo13 && c->qa_mode && !c->att_split_chunks) {
+        // 3 + 4 as ONE launch (launch_wo_w13): the gate/up workgroups stream their weights under the wo rows and poll the new residual
+        GemvArgs w = g, h = g;
+        w.wq = L.wo; w.ws = L.so; w.n = c->att_dim; w.o = a.dim; w.xin = c->att_out; w.out = c->x;
+        w.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+        h.wq = L.w13; h.ws = L.s13; h.n = a.dim; h.o = 2 * a.hidden_dim; h.xin = nullptr; h.rms_w = L.rms_post_att; h.out = c->h;
+        h.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
+        set_launch_tag(3);
+        HIP_OK(launch_wo_w13(w, h, c->xgran + (size_t)l * a.dim, c->seq, c->err, c->stream));
+        goto after_w13;
+    }
     // 3. quantize | Wo | x += ...                                       (:550-576)
     g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -280,6 +293,7 @@ after_wo:
     set_launch_tag(3);
     HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
     g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
+after_w13:
     // 5. quantize | W2 | x += ...                                       (:630-654)
     g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -915,6 +929,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
     c->stage_floats = 64 * dim; need(c->stage_floats * 4); need(64 * 4); need(8 * 1024 * 8); need(512);
     need(nl * (att / 4 + att / 128) * 8);                                              // granules of the three-part launch
+    need(nl * dim * 8);                                                                // granules of the wo + w1/w3 launch
     need(nl * (att_l + 2 * kv_l) * 8); need(256); need(256); need(256); need(kMaxArgmaxParts * 8); need(256);       // granules of the merged qkv + attention launch, step sequence number, error word
     total += 4096;
     HCK(hipMalloc(reinterpret_cast<void**>(&c->arena), total));
@@ -1064,6 +1079,17 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
             if (!c->qgran) { fail("arena overflow"); return cleanup(); }
             HCK(hipMemsetAsync(c->qgran, 0, nl * (att / 4 + att / 128) * 8, c->stream));
             c->wo_merged = true;
+        }
+    }
+    if (c->qkv_att && !c->gemma_fused && !sharded && getenv("LMRS_WO_W13") && atoi(getenv("LMRS_WO_W13")) != 0) {
+        // (LMRS_WO_W13=1, off by default) wo and w1/w3 as one launch - the round-4 prototype of a persistent all-to-all edge, see launch_wo_w13
+        GemvArgs w{}; w.q4 = c->q4; w.n = c->att_dim; w.o = a.dim;
+        GemvArgs h{}; h.q4 = c->q4; h.n = a.dim; h.o = 2 * a.hidden_dim;
+        if (wo_w13_supported(w, h)) {
+            c->xgran = c->alloc<unsigned long long>(nl * dim);
+            if (!c->xgran) { fail("arena overflow"); return cleanup(); }
+            HCK(hipMemsetAsync(c->xgran, 0, nl * dim * 8, c->stream));
+            c->wo13 = true;
         }
     }
     if (!sharded) { const int k = getenv("LMRS_STEPS_PER_GRAPH") ? atoi(getenv("LMRS_STEPS_PER_GRAPH")) : 4; c->multi_k = k < 1 ? 1 : (k > 64 ? 64 : k); }   // (measured: 4 steps per launch +1.5 % on a 20-step run, no effect on long runs)
@@ -1643,7 +1669,7 @@ extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9
             const int kind = tags[i] >= 0 && tags[i] < 9 ? tags[i] : 7;
             us9[kind] += (double)ms * 1e3; count9[kind] += 1;
             const double att_bytes = 2.0 * kv * 4 * ((double)pos + it + 3);                       // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
-            bytes9[kind] += kind == 1 ? att_bytes : wbytes[kind] + (kind == 0 && merged ? att_bytes : 0.0) + (kind == 0 && qmode == 2 && c->wo_merged ? wbytes[2] : 0.0);   // merged launches: everything under kind 0
+            bytes9[kind] += kind == 1 ? att_bytes : wbytes[kind] + (kind == 0 && merged ? att_bytes : 0.0) + (kind == 0 && qmode == 2 && c->wo_merged ? wbytes[2] : 0.0) + (kind == 3 && c->wo13 ? wbytes[2] : 0.0);   // merged launches: everything under the first kind
         }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -1704,7 +1730,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (qa_mode_for(c, pos) && !(c->att_split_pos > 0 && (int)pos >= c->att_split_pos) ? (qa_mode_for(c, pos) == 2 && c->wo_merged ? 3 : 4) : 5)) * (int)a.n_layers + (c->cls_tail ? 1 : 2);
+    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (qa_mode_for(c, pos) && !(c->att_split_pos > 0 && (int)pos >= c->att_split_pos) ? ((qa_mode_for(c, pos) == 2 && c->wo_merged) || c->wo13 ? 3 : 4) : 5)) * (int)a.n_layers + (c->cls_tail ? 1 : 2);
     return 0;
 }
 

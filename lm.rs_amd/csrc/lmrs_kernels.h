@@ -16,14 +16,18 @@ struct DevState {
 
 enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3,   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
                 // merged qkv + attention + wo launch: the quantised attention output arrives as {4 x int8, tag} / {scale, tag} granules written inside the same launch
-                PRO_PREQ_TAG = 4 };
+                PRO_PREQ_TAG = 4,
+                // wo + w1/w3 as one launch (round-4 prototype): the residual stream arrives as {f32, tag} granules the wo workgroups of the SAME launch write
+                PRO_RMS_QUANT_TAG = 5 };
 enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5,
                 // CLIP tower (batched GEMM only): + bias with q / sqrt(head) | + bias + residual | + bias, QuickGELU
                 EPI_VQKV = 6, EPI_BIAS_RESID = 7, EPI_BIAS_QGELU = 8,
                 // image projector (processor.rs:234-342): + bias, tanh-GELU | + bias
                 EPI_BIAS_GELU = 9, EPI_BIAS = 10,
                 // merged qkv + attention launch: q / raw k / v leave as 8-byte {value, tag} granules (write-through), v also to its cache row
-                EPI_QKV_TAG = 11 };
+                EPI_QKV_TAG = 11,
+                // wo + w1/w3 as one launch: x += ..., and every new x value also leaves as a {value, tag} granule
+                EPI_RESID_TAG = 12 };
 
 struct EmbedArgs {
     const void* emb_q; const float* emb_s; int q4;
@@ -130,6 +134,13 @@ hipError_t launch_qkv_attn(const GemvArgs& g, int pro, const AttnArgs& t, int* e
 // wo launch (w.xin unused).  hipErrorNotSupported: no class for this shape.
 bool qkv_attn_wo_supported(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w);
 hipError_t launch_qkv_attn_wo(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w, unsigned long long* qgran, int* err, hipStream_t s);
+// wo + w1/w3 as ONE launch (round-4 prototype of a persistent edge, Llama-3.2-1B Q8_0 shapes): the wo workgroups come first in the grid
+// and publish every new residual value as a granule as well; the gate/up workgroups request their whole weight share (both passes) at
+// kernel start, poll the 2048 granules straight into the registers the norm prologue works on, and run as usual.  w / g: the
+// arguments of the two separate launches (g.xin unused); xgran: dim granules; tiles: 1 = only the first pass's tile before the poll.
+struct WoW13Args { GemvArgs w, g; int n_wo; };
+bool wo_w13_supported(const GemvArgs& w, const GemvArgs& g);
+hipError_t launch_wo_w13(const GemvArgs& w, const GemvArgs& g, unsigned long long* xgran, const unsigned* seq, int* err, hipStream_t s);
 // long contexts: scores by (head, 256-key chunk), softmax + V by (head, quarter of the dims); S: attention_split_scratch_floats(..)
 size_t attention_split_scratch_floats(int n_heads, int seq_len);
 hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks, hipStream_t s);

@@ -692,7 +692,8 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane % L;
     const int o = a.o, n_pass = (o + R::RB - 1) / R::RB;
     const int8_t* wq = reinterpret_cast<const int8_t*>(a.wq);
-    constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT;
+    constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT || PRO == PRO_RMS_QUANT_TAG;
+    constexpr bool XTAG = PRO == PRO_RMS_QUANT_TAG;                                    // x arrives as granules written inside this launch
     constexpr bool PREQ = PRO == PRO_PREQ || PRO == PRO_PREQ_TAG;                      // the activation arrives quantised
 
     unsigned ctag = 0; TailPre tpre{}; int pofs = 0;
@@ -702,11 +703,11 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     }
     int pos_pre = 0; unsigned tag_pre = 0;
     if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_TAG) pos_pre = a.st->pos;      // the kernel's first load: nothing it has to wait behind
-    if constexpr (EPI == EPI_QKV_TAG || PRO == PRO_PREQ_TAG) tag_pre = *a.seq + 1u;
+    if constexpr (EPI == EPI_QKV_TAG || PRO == PRO_PREQ_TAG || EPI == EPI_RESID_TAG || XTAG) tag_pre = *a.seq + 1u;
     float4 v[V::NP], nw[V::NP], dl[V::NP], aw[V::NP];
     if constexpr (!PREQ) {
         if constexpr (PRO == PRO_ADD_RMS_QUANT) { vec_load<N, false, NTH>(dl, a.delta); vec_load<N, false, NTH>(aw, a.add_w); }
-        vec_load<N, false, NTH>(v, a.xin);
+        if constexpr (!XTAG) vec_load<N, false, NTH>(v, a.xin);
         if constexpr (HAS_RMS) vec_load<N, false, NTH>(nw, a.rms_w);
     }
     auto row_of = [&](int pass) __attribute__((always_inline)) { const int rw = pass * R::RB + wave * R::RW + lane / L; return rw < o ? rw : o - 1; };
@@ -715,13 +716,18 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     asm volatile("" ::: "memory");               // keep the activation loads ahead of the weight tile in issue order
     // A CU returns vector-memory data in request order across its waves: without this barrier the activation loads of
     // the workgroup's later waves (L2 hits) queue behind the earlier waves' weight tiles (HBM misses).
-    if (!PREQ && a.order_barrier) __builtin_amdgcn_s_barrier();
+    if (!PREQ && !XTAG && a.order_barrier) __builtin_amdgcn_s_barrier();
     // (waiting for the activation before issuing the tile, or issuing only part of it first, was measured: no gain)
     WTile<R::U> ta, tb;
     int pass = bid;                      // grid <= n_pass
     if constexpr (PRO == PRO_PREQ_TAG) {
         // the workgroups ahead in the grid (the qkv rows) are on the launch's critical path: this tile must not queue in front of theirs
         for (int i = 0; i < a.tag_sleep0; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    if constexpr (XTAG) {
+        // (same for the wo rows ahead of the gate/up workgroups: requested at once, 33 MB of gate/up tiles put the wo rows' 4 MB at the
+        // back of every memory queue - wo finished at 5.1 us instead of 1.4)
+        for (int i = 0; i < a.tag_sleep1; ++i) __builtin_amdgcn_s_sleep(16);
     }
     tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(pass));
     // (requesting the second pass's tile here as well - it would stream under the prologue - was measured slower on every model, Gemma's
@@ -731,7 +737,11 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     // touches it during the launch) and the position the QKV epilogue stores the V row at.
     // (unconditional, every lane of the row: a load under a lane predicate would cost the kernel its counted vmcnt waits)
     float resid0 = 0.0f;
-    if constexpr (EPI == EPI_RESID) resid0 = a.out[row_of(pass)];
+    if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_TAG) resid0 = a.out[row_of(pass)];
+    if constexpr (XTAG) {
+        // the whole weight share before the poll: the second pass's tile too (nothing latency-critical of this workgroup is queued behind it)
+        if (a.tag_sleep0 >= 2) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(bid + nblk));
+    }
     // (two-pass launches: issuing the second tile here as well was measured - slower on every model: the more bytes the
     // chip has in flight, the later every workgroup's activation lands)
     __builtin_amdgcn_sched_barrier(0);           // the prologue's first wait must not be scheduled above the tile's loads
@@ -746,6 +756,34 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
         for (int g = threadIdx.x; g < V::G; g += NTH) xs[g] = preq_scale(a, g);
     } else {
         unsigned long long* dbg = bid == 0 ? a.dbg : nullptr;
+        if constexpr (XTAG) {
+            // every lane polls the granules of the 4 x NP values it owns (the whole workgroup: all N); a wave leaves when its own are this
+            // step's - the norm's first barrier then joins the waves.  Bounded (err).
+            static_assert(V::FULL, "granule hand-off: whole passes");
+            const unsigned long long* gp = a.gran_in + threadIdx.x * 4;
+            unsigned long long x[V::NP][4];
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < V::NP; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[i][k] = __hip_atomic_load(gp + i * V::PER + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int i = 0; i < V::NP; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ok = ok && (unsigned)(x[i][k] >> 32) == tag_pre;
+                if (__all(ok)) break;
+                if (spins > kTagSpinMax || (spins & 1023) == 1023) {
+                    const int e = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e != 0 || spins > kTagSpinMax) { if (e == 0) __hip_atomic_store(a.err, 4000 + a.layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+#pragma unroll
+            for (int i = 0; i < V::NP; ++i)
+                v[i] = make_float4(__uint_as_float((unsigned)x[i][0]), __uint_as_float((unsigned)x[i][1]), __uint_as_float((unsigned)x[i][2]), __uint_as_float((unsigned)x[i][3]));
+            if (dbg && threadIdx.x == 0) dbg[6] = wall_clock64();
+        }
         if constexpr (PRO == PRO_ADD_RMS_QUANT) {
             // (Round 4, measured and removed: requesting the second pass's tile from inside this ~5 us prologue, once the branch output has
             // landed.  Gemma-2-2B Q4_0: 889 -> 894 us per step with three passes per workgroup, 898 -> 952 with two - the tiles of 288
@@ -776,6 +814,12 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
             if (valid && writer) a.out[row] = acc;
         } else if constexpr (EPI == EPI_RESID) {
             if (valid && writer) a.out[row] = (ps == bid ? resid0 : a.out[row]) + acc;
+        } else if constexpr (EPI == EPI_RESID_TAG) {
+            if (valid && writer) {
+                const float xn = (ps == bid ? resid0 : a.out[row]) + acc;
+                a.out[row] = xn;                                                     // for the launches that follow
+                __hip_atomic_store(a.gran + row, ((unsigned long long)tag_pre << 32) | __float_as_uint(xn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the gate/up workgroups of THIS launch
+            }
         } else if constexpr (EPI == EPI_QKV) {
             if (valid && writer) {
                 if (row < a.att_dim) a.out[row] = acc;
@@ -817,7 +861,7 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
         for (;;) {
             const int p1 = pass + nblk;
             const bool have1 = p1 < n_pass;
-            if (have1) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));
+            if (have1 && !(XTAG && a.tag_sleep0 >= 2 && pass == bid)) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));     // (XTAG: on its way since kernel start)
             const float acc_a = tile_consume<N, L, Q4>(ta, xq, xs);
             if (pass == bid) LMRS_STAMP0(2);
             const int p2 = p1 + nblk;
@@ -1983,6 +2027,39 @@ hipError_t launch_qkv_attn_wo(const GemvArgs& g0, int pro, const AttnArgs& t0, c
     LMRS_QAW_TABLE(X)
 #undef X
     return hipErrorNotSupported;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wo + w1/w3 as ONE launch (round-4 prototype of a persistent all-to-all edge; LMRS_WO_W13=1).  Workgroups [0, n_wo): the wo GEMV,
+// unchanged but for its epilogue (EPI_RESID_TAG: x also leaves as granules).  The gate/up workgroups behind them request their weight
+// tiles at kernel start - the stream that otherwise begins one boundary + one ramp after wo's last store runs under wo - then poll the
+// 2048 granules into the registers of the norm prologue (PRO_RMS_QUANT_TAG).  All workgroups are resident at once (3 per CU at 168
+// VGPRs); nobody waits for a workgroup behind it; polls are bounded.  Arithmetic: the two static bodies - bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int NW_, int LW, int N, int L>
+__global__ __launch_bounds__(kBlock) void wo_w13_kernel(const WoW13Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = (int)blockIdx.x;
+    if (b < a.n_wo) gemv_static_body<NW_, LW, PRO_QUANT, EPI_RESID_TAG, kBlock, false>(a.w, smem, b, a.n_wo);
+    else gemv_static_body<N, L, PRO_RMS_QUANT_TAG, EPI_SWIGLU, kBlock, false>(a.g, smem, b - a.n_wo, (int)gridDim.x - a.n_wo);
+}
+bool wo_w13_supported(const GemvArgs& w, const GemvArgs& g) {
+    if (w.q4 || g.q4 || w.n != 2048 || w.o != 2048 || g.n != 2048 || g.o != 16384) return false;
+    const StaticClass sw = static_class(w, PRO_QUANT, EPI_RESID), sg = static_class(g, PRO_RMS_QUANT, EPI_SWIGLU);
+    return sw.L == 32 && sw.nt == kBlock && sg.L == 16 && sg.nt == kBlock;
+}
+hipError_t launch_wo_w13(const GemvArgs& w0, const GemvArgs& g0, unsigned long long* xgran, const unsigned* seq, int* err, hipStream_t s) {
+    if (!wo_w13_supported(w0, g0) || !xgran || !seq || !err) return hipErrorNotSupported;
+    WoW13Args a{w0, g0, 0};
+    a.w.order_barrier = env_flag("LMRS_ORDER_BARRIER", 1); a.g.order_barrier = 0; a.g.chain_spread = env_flag("LMRS_CHAIN_SPREAD", 1);
+    a.w.gran = xgran; a.w.seq = seq; a.g.gran_in = xgran; a.g.seq = seq; a.g.err = err;
+    a.g.tag_sleep0 = env_flag("LMRS_WO_W13_TILES", 2); a.g.tag_sleep1 = env_flag("LMRS_WO_W13_SLEEP", 3);
+    a.n_wo = gemv_grid(a.w, PRO_QUANT, EPI_RESID);
+    const int n13 = gemv_grid(a.g, PRO_RMS_QUANT, EPI_SWIGLU);
+    size_t smem = gemv_smem(a.w, PRO_QUANT); const size_t s2 = gemv_smem(a.g, PRO_RMS_QUANT);
+    if (s2 > smem) smem = s2;
+    LMRS_LAUNCH_GRID((wo_w13_kernel<2048, 32, 2048, 16>), dim3(a.n_wo + n13), kBlock, smem, s, a);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -837,6 +837,11 @@ def test_merged_qkv_attention_launch_and_classifier_tail(L, monkeypatch, cfg, q)
         assert m2.step_info(0)[0] == 3 * nl + 1 and m2.step_info(200)[0] == 4 * nl + 1
         assert (m2.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: wo inside the merged launch (three-part form)"
         monkeypatch.delenv("LMRS_WO_MERGED")
+        monkeypatch.setenv("LMRS_WO_W13", "1")                # wo + w1/w3 as one launch (the round-4 prototype of a persistent edge; off by default: slower)
+        m3 = L.Transformer(img)
+        assert m3.step_info(0)[0] == 3 * nl + 1 and m3.step_info(200)[0] == 3 * nl + 1
+        assert (m3.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: wo + w1/w3 as one launch"
+        monkeypatch.delenv("LMRS_WO_W13")
     monkeypatch.setenv("LMRS_QKV_ATT", "0"); monkeypatch.setenv("LMRS_CLS_TAIL", "0")
     m0 = L.Transformer(img)
     assert m0.step_info(0)[0] == 5 * nl + 2

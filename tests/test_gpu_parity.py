@@ -853,6 +853,34 @@ def test_merged_qkv_attention_launch_and_classifier_tail(L, monkeypatch, cfg, q)
         assert m.forward_argmax(int(toks[pos]), pos) == int(toks[pos + 1]) or pos < len(prompt) - 1
 
 
+def test_classifier_tags_survive_2047_layers_only_steps(L, monkeypatch):
+    """The folded argmax tags its packed partials with 11 bits of a counter.  That counter used to be the step counter, which the
+    layers-only steps of a token-by-token fill bump as well: exactly 2047 of them between two decode steps made the previous step's
+    partials look current.  The tags now count classifier launches only: decode, 2047 fill steps (32 fills over the same positions),
+    decode - the token and the logits of the second decode step are the CPU path's."""
+    monkeypatch.setenv("LMRS_NO_BATCHED_PREFILL", "1")
+    cfg = "mini-llama"
+    img = S.build_image(cfg, S.Q8_0, seed=91)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    t0 = 17
+    first = m.forward_argmax(t0, 0)
+    lo0 = orc.forward(t0, 0)
+    assert first == int(O.lib().lmrs_ref_argmax(lo0.ctypes.data, lo0.size))
+    toks = S.prompt_tokens(cfg, 64, 92)
+    emb = m.get_embeddings(toks)
+    done = 0
+    for k in range(32):                                       # 31 x 64 + 63 = 2047 layers-only steps
+        n = 64 if k < 31 else 63
+        assert m.fill_kv_cache(emb[: n * m.args.dim].copy(), 1) == 1 + n
+        done += n
+    assert done == 2047
+    e2 = orc.get_embeddings(toks[:63])
+    assert orc.fill_kv_cache(e2, 1) == 64                     # (the fills rewrite the same rows with the same values: one suffices here)
+    lo = orc.forward(int(first), 64)
+    assert m.forward_argmax(int(first), 64) == int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
+    assert_bit_equal(m.forward(int(first), 64), lo, "logits after the 2047 layers-only steps")
+
+
 # ------------------------------------------------------------------ error behaviour (reference: panics)
 def test_errors(L):
     img = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "tiny_llama_q8.lmrs"), np.uint8)

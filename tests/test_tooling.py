@@ -1,6 +1,5 @@
 """Measurement tooling that the round's artefacts depend on (no GPU): the profile summaries bench.py quotes are the ones of the
-committed sources, the summary scripts reproduce the committed summaries from the committed raw statistics, and the next-round
-patches under tools/ubench still apply."""
+committed sources, the summary scripts reproduce the committed summaries from the committed raw statistics, (keyed by the hash of the kernel sources)."""
 import glob
 import json
 import os
@@ -14,9 +13,11 @@ sys.path.insert(0, ROOT)
 
 
 def test_rocprof_summary_is_reproducible_from_the_committed_statistics(tmp_path):
-    """tools/rocprof_summary.py over profiles/r3_kernel_stats.csv gives the per-step figure recorded in profiles/r3_rocprof_llama1b_q8.json."""
-    stats = os.path.join(ROOT, "profiles", "r3_kernel_stats.csv")
-    ref = json.load(open(os.path.join(ROOT, "profiles", "r3_rocprof_llama1b_q8.json")))
+    """tools/rocprof_summary.py over the newest profiles/rN_kernel_stats.csv gives the per-step figure recorded in the same round's
+    profiles/rN_rocprof_llama1b_q8.json."""
+    ref_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_llama1b_q8.json")))[-1]
+    stats = ref_path.replace("_rocprof_llama1b_q8.json", "_kernel_stats.csv")
+    ref = json.load(open(ref_path))
     out = tmp_path / "s.json"
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), stats, str(out), "llama-3.2-1b", "q8_0"], check=True, cwd=ROOT)
     got = json.load(open(out))
@@ -33,12 +34,12 @@ def test_bench_reads_the_profile_summaries_when_the_source_hash_matches():
     state of the tree, the lookup must be consistent with the stamps."""
     import bench
     h = bench.kernel_source_hash()
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic_llama1b_q8.json")))
-    rp = json.load(open(os.path.join(ROOT, "profiles", "r3_rocprof_llama1b_q8.json")))
+    newest_tr = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_llama1b_q8.json")))[-1]
+    tr = json.load(open(newest_tr))
+    rp = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_llama1b_q8.json")))[-1]))
     t = bench.pmc_traffic("llama-3.2-1b", "q8_0")
     r = bench.rocprof_family_us("llama-3.2-1b", "q8_0")
-    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic_llama1b_q8.json")))[-1]
-    if tr["kernel_source_hash"] == h and newest.endswith("r3_traffic_llama1b_q8.json"):
+    if tr["kernel_source_hash"] == h:
         assert t is not None and t > 1e7
     if tr["kernel_source_hash"] != h:
         assert t is None or t > 0          # (an older summary with a matching hash may exist; never a mismatching one)

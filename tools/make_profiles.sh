@@ -2,11 +2,12 @@
 # Regenerates the round's measurement artefacts on a GPU box (run from the repo root through gpurun); everything lands in
 # gpurun_out/art/ and is copied into profiles/ by hand afterwards.  PMC counters are collected in their own rocprofv3 runs
 # (--kernel-trace only, one counter per pass), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-#   usage: bash tools/make_profiles.sh <tag> [pmc]      (e.g. r3; `pmc`: only the counter passes and the bench lines that quote them)
+#   usage: bash tools/make_profiles.sh <tag> [pmc]      (e.g. r4; `pmc`: only the counter passes and the bench lines that quote them)
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
+export LMRS_BENCH_IMAGE_CACHE=/tmp          # the synthetic images are built once, outside the profiler
 OUT=gpurun_out/art; ONLY=${2:-all}
 if [ "$ONLY" = all ]; then rm -rf $OUT; fi
 mkdir -p $OUT
@@ -16,7 +17,8 @@ pmc() {   # model qtype out-json
         # and it segfaults now and then at start-up whatever the workload - or hangs: a pass that works takes 25 s, so 60 s per try, up to three tries)
         for try in 1 2 3; do
             rm -rf $OUT/pmc_$1_$c
-            LMRS_STEPS_PER_GRAPH=1 timeout -k 5 60 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
+            KT=--kernel-trace; [ $try = 3 ] && KT=            # (last try: counters alone - the trace + counter combination is what crashed on Gemma-2-2B in round 3)
+            LMRS_STEPS_PER_GRAPH=1 timeout -k 5 90 rocprofv3 $KT --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
             ls $OUT/pmc_$1_$c/*/*counter_collection.csv > /dev/null 2>&1 && break
         done
     done
@@ -26,7 +28,19 @@ pmc() {   # model qtype out-json
     cp $3 profiles/                                   # bench.py reads profiles/*traffic*.json (matching model / qtype / source hash)
     rm -rf $OUT/pmc_$1_FETCH_SIZE $OUT/pmc_$1_WRITE_SIZE
 }
-pmc llama-3.2-1b q8_0 $OUT/${TAG}_traffic_llama1b_q8.json
+stats() {   # model qtype short-name: their bench line (which also leaves the image in the cache), then rocprofv3 kernel statistics of the same 64-step bench
+    timeout 400 python bench.py --model $1 --qtype $2 --steps 64 > $OUT/${TAG}_bench_$3.json 2>> $OUT/bench.err
+    for try in 1 2 3; do                                # (rocprofv3 1.1 segfaults at start-up now and then, whatever the workload)
+        rm -rf $OUT/st_$3
+        # (one step per graph launch: with the 26-32-layer models' four-step graphs - 420 to 516 nodes - rocprofv3 1.1 segfaults at capture, every time)
+        LMRS_STEPS_PER_GRAPH=1 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$3 -- python bench.py --model $1 --qtype $2 --steps 64 --cpu-steps 0 > $OUT/st_$3.log 2>&1
+        ls $OUT/st_$3/*/*kernel_stats.csv > /dev/null 2>&1 && break
+    done
+    cp $(ls $OUT/st_$3/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats_$3.csv 2>/dev/null; rm -rf $OUT/st_$3
+}
+if [ "$ONLY" != extra ]; then pmc llama-3.2-1b q8_0 $OUT/${TAG}_traffic_llama1b_q8.json; fi
+if [ "$ONLY" = extra ]; then stats gemma-2-2b q4_0 gemma2b_q4; pmc gemma-2-2b q4_0 $OUT/${TAG}_traffic_gemma2b_q4.json; stats llama-3.2-3b q8_0 llama3b; stats phi-3.5 q8_0 phi35; exit 0; fi
+timeout 300 python bench.py --model gemma-2-2b --qtype q4_0 --steps 4 --cpu-steps 0 > /dev/null 2>&1      # (image into the cache)
 pmc gemma-2-2b q4_0 $OUT/${TAG}_traffic_gemma2b_q4.json
 if [ "$ONLY" = pmc ]; then timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2>> $OUT/bench.err; exit 0; fi
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
@@ -35,9 +49,9 @@ cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv; 
 python tools/rocprof_summary.py $OUT/${TAG}_kernel_stats.csv $OUT/${TAG}_rocprof_llama1b_q8.json llama-3.2-1b q8_0 && cp $OUT/${TAG}_rocprof_llama1b_q8.json profiles/   # bench.py reads it (frac_rocprof)
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err                      # again: now with frac_rocprof and traffic of this build
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2>> $OUT/bench.err   # the driver's invocation
-timeout 300 python bench.py --model gemma-2-2b --qtype q4_0 --steps 64 > $OUT/${TAG}_bench_gemma2b_q4.json 2>> $OUT/bench.err
-timeout 400 python bench.py --model llama-3.2-3b --steps 64 > $OUT/${TAG}_bench_llama3b.json 2>> $OUT/bench.err
-timeout 400 python bench.py --model phi-3.5 --steps 64 > $OUT/${TAG}_bench_phi35.json 2>> $OUT/bench.err
+stats gemma-2-2b q4_0 gemma2b_q4
+stats llama-3.2-3b q8_0 llama3b
+stats phi-3.5 q8_0 phi35
 timeout 200 python tools/timeline.py llama-3.2-1b 100 > $OUT/${TAG}_timeline_llama1b.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf -- python tools/prefill_rate.py llama-3.2-1b 512 > $OUT/${TAG}_prefill512.log 2>&1
 cp $(ls $OUT/pf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prefill512_kernel_stats.csv; rm -rf $OUT/pf

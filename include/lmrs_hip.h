@@ -187,6 +187,9 @@ int lmrs_debug_timeline(lmrs_ctx* ctx, unsigned long long* out, int max_nodes, i
 /* Verification aid (no reference counterpart; the reference's key_cache / value_cache are private, transformer.rs:302-303): one row of
  * the KV cache as the reference lays it out (which: 0 key, 1 value; kv_dim floats of `layer` at `pos`). */
 int lmrs_debug_kv(lmrs_ctx* ctx, int which, uint32_t layer, uint32_t pos, float* out);
+/* Device time (ms, HIP events) the last BATCHED lmrs_fill_kv_cache of this context spent between the upload of its embeddings and the
+ * download of the residual stream: forward_layer(sl = n) itself.  Measurement aid (bench.py's `prefill` object), no reference counterpart. */
+int lmrs_last_fill_ms(const lmrs_ctx* ctx, double* ms);
 /* Fault injection for the tests of the multi-GPU paths (no reference counterpart; explicit calls, nothing is read from the environment):
  *   what = 0: the next lmrs_p2p_connect of this context fails ("injected failure"), so that a launcher's "every rank falls back
  *             together" logic can be exercised;

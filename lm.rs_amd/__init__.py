@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv", "lmrs_debug_inject",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv", "lmrs_debug_inject", "lmrs_last_fill_ms",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_comm_ranks", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
@@ -126,6 +126,7 @@ def lib():
         L.lmrs_op_sample_mult.argtypes = [C.c_int, vp, sz, C.c_float, C.c_float, C.POINTER(u32)]
         L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
         L.lmrs_debug_inject.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.lmrs_last_fill_ms.argtypes = [vp, C.POINTER(C.c_double)]
         L.lmrs_p2p_handle.argtypes = [vp, vp]
         L.lmrs_p2p_connect.argtypes = [vp, vp]
         L.lmrs_bench_step.argtypes = [vp, u32, C.c_int, vp, vp, vp]
@@ -216,6 +217,12 @@ class Transformer:
         out = np.empty(self.args.n_kv_heads * self.args.head_size, np.float32)
         _chk(lib().lmrs_debug_kv(self._h, which, layer, pos, _p(out)))
         return out
+
+    def last_fill_ms(self) -> float:
+        """device milliseconds of the last batched fill_kv_cache without its host <-> device copies (lmrs_last_fill_ms)"""
+        ms = C.c_double()
+        _chk(lib().lmrs_last_fill_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def debug_inject(self, what: int, a: int = 0, b: int = 0) -> None:
         """Fault injection for the multi-GPU tests (include/lmrs_hip.h: lmrs_debug_inject)."""

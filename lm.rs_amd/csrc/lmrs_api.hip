@@ -98,6 +98,7 @@ struct lmrs_ctx {
     // a shard pushes its block straight into its peers' copies (xGMI stores) and raises a flag there (exchange_push_kernel)
     bool p2p = false, p2p_ready = false; char* xarena = nullptr; size_t xarena_bytes = 0; char* peer_base[kMaxWorld] = {};
     unsigned *xflags = nullptr, *xseq = nullptr; int* xerr = nullptr; int ex_slot = 0; bool xarena_is_ipc[kMaxWorld] = {};
+    double last_fill_ms = -1.0;                    // device time of the last batched fill_kv_cache between its upload and its download (lmrs_last_fill_ms)
     void* topp_pairs = nullptr;                    // lmrs_forward_sample, top-p: vocab_size (prob, index) pairs + the filter's counts (allocated on first use)
     bool err_queued = false;                       // the error word's copy to h_err rides in front of the call's own synchronise (queue_err)
     int* err = nullptr; int* h_err = nullptr;      // error word of the bounded in-launch waits (merged qkv + attention launch, classifier tail)
@@ -1456,13 +1457,16 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
         for (uint32_t i0 = 0; i0 < n; i0 += kPrefillTokens) {
             const int m = (int)std::min<uint32_t>(kPrefillTokens, n - i0);
             HIP_OK(hipMemcpyAsync(c->pf_x, embeddings + (size_t)i0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, c->stream));
+            if (i0 == 0) HIP_OK(hipEventRecord(c->ev0, c->stream));                     // (measurement: the layers without the first upload / the last download)
             if (prefill_layers(c, m, (int)(curr_pos + i0))) return -1;
+            if (i0 + kPrefillTokens >= n) HIP_OK(hipEventRecord(c->ev1, c->stream));
             HIP_OK(hipMemcpyAsync(embeddings + (size_t)i0 * dim, c->pf_x, (size_t)m * dim * 4, hipMemcpyDeviceToHost, c->stream));
         }
         if (set_state(c, curr_pos + n, 0)) return -1;
         if (queue_err(c)) return -1;
         HIP_OK(hipStreamSynchronize(c->stream));
         if (check_err(c)) return -1;
+        { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_fill_ms = ms; }
         if (new_pos) *new_pos = curr_pos + n;
         return 0;
     }
@@ -1703,6 +1707,13 @@ extern "C" int lmrs_debug_kv(lmrs_ctx* c, int which, uint32_t layer, uint32_t po
     const float* kl = c->k_cache + (size_t)layer * nkv * hs * S;
     for (size_t h = 0; h < nkv; ++h)
         HIP_OK(hipMemcpy2D(out + h * hs, 16, kl + h * hs * S + pos * 4, S * 16, 16, hs / 4, hipMemcpyDeviceToHost));   // hs/4 words of 4 dims, S*16 bytes apart
+    return 0;
+}
+
+extern "C" int lmrs_last_fill_ms(const lmrs_ctx* c, double* ms) {
+    if (!c || !ms) return fail("NULL argument");
+    if (c->last_fill_ms < 0) return fail("no batched fill_kv_cache has run on this context");
+    *ms = c->last_fill_ms;
     return 0;
 }
 

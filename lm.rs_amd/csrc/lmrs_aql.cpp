@@ -205,7 +205,8 @@ struct AqlProgram {
     int device = 0;
     struct Pkt { uint64_t object; void* kernarg; uint32_t grid[3]; uint16_t block; uint32_t group, priv; };
     std::vector<Pkt> pkts;
-    char* kargs = nullptr;                                   // device memory: one block per packet
+    char* kargs = nullptr;                                   // device memory (or pinned host memory): one block per packet
+    bool host_kargs = false;
 };
 
 AqlProgram* aql_program_create(int device, const AqlRecorder& rec, std::string* err) {
@@ -246,8 +247,12 @@ AqlProgram* aql_program_create(int device, const AqlRecorder& rec, std::string* 
     }
     AqlProgram* p = new AqlProgram();
     p->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&p->kargs), total) != hipSuccess ||
-        hipMemcpy(p->kargs, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) {
+    // LMRS_AQL_HOST_KERNARG=1: the argument blocks in pinned host memory instead of device memory - rocprofv3's queue interceptor copies
+    // every packet's argument block on the HOST and segfaults on a device address (the profiling recipe sets it; a few percent slower)
+    p->host_kargs = getenv("LMRS_AQL_HOST_KERNARG") && atoi(getenv("LMRS_AQL_HOST_KERNARG")) != 0;
+    if (hipSetDevice(device) != hipSuccess ||
+        (p->host_kargs ? hipHostMalloc(reinterpret_cast<void**>(&p->kargs), total, hipHostMallocDefault) : hipMalloc(reinterpret_cast<void**>(&p->kargs), total)) != hipSuccess ||
+        hipMemcpy(p->kargs, host.data(), total, p->host_kargs ? hipMemcpyHostToHost : hipMemcpyHostToDevice) != hipSuccess) {
         if (err) *err = "hipMalloc / hipMemcpy of the argument blocks failed";
         aql_program_destroy(p);
         return nullptr;
@@ -261,7 +266,7 @@ AqlProgram* aql_program_create(int device, const AqlRecorder& rec, std::string* 
 
 void aql_program_destroy(AqlProgram* p) {
     if (!p) return;
-    if (p->kargs) (void)hipFree(p->kargs);
+    if (p->kargs) (void)(p->host_kargs ? hipHostFree(p->kargs) : hipFree(p->kargs));
     delete p;
 }
 int aql_program_launches(const AqlProgram* p) { return p ? (int)p->pkts.size() : 0; }

@@ -21,17 +21,59 @@ __device__ __forceinline__ int cluster8_sum(int v) {
     v += dpp_i<0x141>(v);
     return v;
 }
-// Max over each aligned group of 32 lanes (one 128-element quantisation group at 4 elements per lane).
-__device__ __forceinline__ float group32_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));
-    v = fmaxf(v, dpp_f<0x140>(v));
-    // lanes l and l^16: gfx950's v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of
-    // another (VALU, no LDS round trip): with both registers = v the results are [r0 r0 r2 r2] and [r1 r1 r3 r3]
-    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+// v = max(v, v of another lane) as ONE instruction: the DPP operand of the max itself.  (Spelled fmaxf(v, dpp_f(v)) hipcc emits three -
+// v_mov_b32_dpp, a canonicalising v_max v, v, v of the moved value, then the max: the quantiser's group maxima were 68 of the 249
+// vector instructions of w2's prologue.)  IEEE v_max_f32: a NaN operand is dropped, as f32::max does (quantization.rs:52).
+#ifndef LMRS_NO_ASM_MAX
+#define LMRS_DPP_MAX(name, ctrl)                                                                                       \
+    __device__ __forceinline__ float name(float v) {                                                                   \
+        float r;                                                                                                       \
+        /* s_nop 1: a DPP operand must not be read sooner than two wait states after a VALU wrote it, and hipcc's hazard    */ \
+        /* recogniser does not know this asm reads through DPP (it put ONE state between two of these: wrong maxima)         */ \
+        asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));               \
+        return r;                                                                                                      \
+    }
+#else
+#define LMRS_DPP_MAX(name, ctrl) __device__ __forceinline__ float name(float v);
+#endif
+LMRS_DPP_MAX(max_quad1, "quad_perm:[1,0,3,2]")
+LMRS_DPP_MAX(max_quad2, "quad_perm:[2,3,0,1]")
+LMRS_DPP_MAX(max_half_mirror, "row_half_mirror")
+LMRS_DPP_MAX(max_mirror, "row_mirror")
+#ifdef LMRS_NO_ASM_MAX
+__device__ __forceinline__ float max_quad1(float v) { return fmaxf(v, dpp_f<0xB1>(v)); }
+__device__ __forceinline__ float max_quad2(float v) { return fmaxf(v, dpp_f<0x4E>(v)); }
+__device__ __forceinline__ float max_half_mirror(float v) { return fmaxf(v, dpp_f<0x141>(v)); }
+__device__ __forceinline__ float max_mirror(float v) { return fmaxf(v, dpp_f<0x140>(v)); }
+#endif
+// max(|a.x|, |a.y|, |a.z|, |a.w|, m) in two instructions (the source modifiers are free; fmaxf(fabsf()) canonicalises every input first)
+__device__ __forceinline__ float absmax4(const float4& a, float m) {
+#ifndef LMRS_NO_ASM_MAX
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a.x), "v"(a.y), "v"(m));
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a.z), "v"(a.w), "v"(r));
+    return r;
+#else
+    return fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), m);
+#endif
 }
+// Max over each aligned cluster of LG lanes (LG = 4 .. 32); every lane of the cluster gets it.
+template <int LG> __device__ __forceinline__ float cluster_max(float v) {
+    static_assert(LG == 4 || LG == 8 || LG == 16 || LG == 32, "cluster of 4, 8, 16 or 32 lanes");
+    v = max_quad1(v);
+    v = max_quad2(v);
+    if constexpr (LG >= 8) v = max_half_mirror(v);
+    if constexpr (LG >= 16) v = max_mirror(v);
+    if constexpr (LG == 32) {
+        // lanes l and l^16: gfx950's v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of
+        // another (VALU, no LDS round trip): with both registers = v the results are [r0 r0 r2 r2] and [r1 r1 r3 r3]
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    return v;
+}
+// Max over each aligned group of 32 lanes (one 128-element quantisation group at 4 elements per lane).
+__device__ __forceinline__ float group32_max(float v) { return cluster_max<32>(v); }
 
 // Max over the whole wave: the two 32-lane halves meet through gfx950's v_permlane32_swap (VALU, no LDS round trip).
 __device__ __forceinline__ float wave64_max(float v) {
@@ -198,7 +240,31 @@ __device__ __forceinline__ int quant_q8_try(float x, float inv, float& dev) {   
     dev = __builtin_fmaxf(dev, fabsf(r - n));
     return (int)n;
 }
-__device__ __forceinline__ bool quant_slow(float wmax, float dev) { return !quant_group_sane(wmax) || dev > 0.4999f; }
+// m / 127 correctly rounded, without the 12-instruction IEEE division sequence: y = RN(1/127), q0 = m y, r = m - 127 q0 (exact, one
+// FMA), q = q0 + r y (one FMA).  oracle/quant_check.c: equal to m / 127.0f for EVERY float in [1e-30, 1e30] (1.67e9 cases) - the range
+// quant_group_sane admits; every other group goes through the slow path, which divides.
+__device__ __forceinline__ float div127_sane(float m) {
+#ifndef LMRS_NO_FAST_DIV127
+    const float y = 0x1.020408p-7f;
+    const float q0 = m * y;
+    const float r = __builtin_fmaf(-127.0f, q0, m);
+    return __builtin_fmaf(r, y, q0);
+#else
+    return m / 127.0f;
+#endif
+}
+
+// (the window: the product is provably within 3.1e-5 of the quotient - 1 ulp of v_rcp_f32, the product's and the division's roundings at
+// |q| <= 127 - so 4e-5 suffices; round 3 used 1e-4, and every hit is on the critical path of a launch: all workgroups quantise the same vector)
+constexpr float kQuantDevMax = 0.49996f;
+__device__ __forceinline__ bool quant_slow(float wmax, float dev) { return !quant_group_sane(wmax) || dev > kQuantDevMax; }
+// candidate + its distance from the integer it was rounded to (the caller flags |d| > kQuantDevMax)
+__device__ __forceinline__ int quant_q8_cand(float x, float inv, float& d) {
+    const float r = x * inv;
+    const float n = rintf(r);
+    d = r - n;
+    return (int)n;
+}
 // ((x/scale + 8.0).round() as u8).clamp(0, 15)
 __device__ __forceinline__ unsigned quant_q4(float x, float scale) {
     float q = roundf(x / scale + 8.0f);
@@ -214,6 +280,14 @@ __device__ __forceinline__ unsigned quant_q4_try(float x, float inv, float& dev)
     const float n = rintf(s);
     dev = __builtin_fmaxf(dev, fabsf(s - n));
     const unsigned q = (unsigned)(int)n;                         // n >= -0.0
+    return q < 15u ? q : 15u;
+}
+
+__device__ __forceinline__ unsigned quant_q4_cand(float x, float inv, float& d) {
+    const float s = x * inv + 8.0f;
+    const float n = rintf(s);
+    d = s - n;
+    const unsigned q = (unsigned)(int)n;
     return q < 15u ? q : 15u;
 }
 

@@ -665,6 +665,16 @@ __device__ __forceinline__ void preq_poll(const GemvArgs& a, int8_t* xq, float* 
     }
 }
 
+// The value of lane i + D (D = 8 / 16: the up row of a gate row of L = D lanes) without the LDS crossbar round trip of __shfl_down:
+// row_shl:8 inside a 16-lane row; across rows gfx950's v_permlane16_swap (with both operands = v its second result is [r1 r1 r3 r3]).
+template <int D> __device__ __forceinline__ float lane_plus(float v) {
+    if constexpr (D == 8) return dpp_f<0x108>(v);
+    else if constexpr (D == 16) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(sw[1]);
+    } else return __shfl_down(v, D);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Static-shape fused dequant-GEMV (Q8_0): N, L compile-time (lmrs_stage.h).  One tile (U = groups per
 // cluster) covers a lane's whole share of a row; pass p handles rows p*RB .. p*RB+RB-1.
@@ -760,14 +770,14 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
             // every lane polls the granules of the 4 x NP values it owns (the whole workgroup: all N); a wave leaves when its own are this
             // step's - the norm's first barrier then joins the waves.  Bounded (err).
             static_assert(V::FULL, "granule hand-off: whole passes");
-            const unsigned long long* gp = a.gran_in + threadIdx.x * 4;
+            const unsigned long long* gp = a.gran_in;
             unsigned long long x[V::NP][4];
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
 #pragma unroll
                 for (int i = 0; i < V::NP; ++i)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) x[i][k] = __hip_atomic_load(gp + i * V::PER + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < 4; ++k) x[i][k] = __hip_atomic_load(gp + V::elem(i, (int)threadIdx.x) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int i = 0; i < V::NP; ++i)
 #pragma unroll
@@ -792,7 +802,7 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
 #pragma unroll
             for (int i = 0; i < V::NP; ++i) {
                 v[i].x = v[i].x + dl[i].x; v[i].y = v[i].y + dl[i].y; v[i].z = v[i].z + dl[i].z; v[i].w = v[i].w + dl[i].w;   // x[i] += emb[i]
-                const int e = i * V::PER + (int)threadIdx.x * 4;
+                const int e = V::elem(i, (int)threadIdx.x);
                 if (bid == 0 && (V::FULL || i < V::NP - 1 || e < N)) *reinterpret_cast<float4*>(a.xout + e) = v[i];
             }
         }
@@ -857,7 +867,8 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     if constexpr (EPI == EPI_SWIGLU || EPI == EPI_GELU) {
         // Gate/up launches: the activation (SiLU: glibc expf in double; GELU: an f64 tanh, ~230 instructions) costs the WAVE its
         // whole instruction stream however few lanes need it, and only one lane in 2L holds a (gate, up) pair.  So the passes are
-        // taken two at a time: the second pass's pair moves one lane up (DPP row_shr:1, same 16-lane row) and ONE evaluation serves both.
+        // taken up to three at a time: the second pass's pair moves one lane up, the third's two (DPP row_shr, same 16-lane row) and
+        // ONE evaluation serves all of them (three since round 4: Gemma-2-2B's three passes per workgroup paid two evaluations).
         for (;;) {
             const int p1 = pass + nblk;
             const bool have1 = p1 < n_pass;
@@ -871,19 +882,39 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
                 if (have2) tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(p2));
                 acc_b = tile_consume<N, L, Q4>(tb, xq, xs);
             }
-            const float up_a = __shfl_down(acc_a, L), up_b = __shfl_down(acc_b, L);          // rows interleaved: 2i gate, 2i+1 up
+            const int p3 = p2 + nblk;
+            const bool have3 = have2 && p3 < n_pass;
+            float acc_c = 0.0f;
+#ifndef LMRS_GLU_PAIRS
+            if (have2) {                                                   // wave-uniform
+                if (have3) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p3));
+                acc_c = tile_consume<N, L, Q4>(ta, xq, xs);
+            }
+            const bool third = have2;
+#else
+            const bool third = false;
+#endif
+            const float up_a = lane_plus<L>(acc_a), up_b = lane_plus<L>(acc_b), up_c = lane_plus<L>(acc_c);         // rows interleaved: 2i gate, 2i+1 up
             const float gate_b1 = dpp_f<0x111>(acc_b), up_b1 = dpp_f<0x111>(up_b);           // pass B's pair, one lane up
+            const float gate_c2 = dpp_f<0x112>(acc_c), up_c2 = dpp_f<0x112>(up_c);           // pass C's pair, two lanes up
             const bool lane_a = writer && ((lane / L) & 1) == 0;                            // holds pass A's pair
             const bool lane_b = have1 && (r == R::WR + 1) && ((lane / L) & 1) == 0;         // its neighbour: pass B's pair
-            const float gate = lane_b ? gate_b1 : acc_a, up = lane_b ? up_b1 : up_a;
+            const bool lane_c = third && (r == R::WR + 2) && ((lane / L) & 1) == 0;         // the next one: pass C's pair
+            const float gate = lane_c ? gate_c2 : lane_b ? gate_b1 : acc_a, up = lane_c ? up_c2 : lane_b ? up_b1 : up_a;
             float hval;
             if constexpr (EPI == EPI_SWIGLU) hval = swiglu_t(gate, up, etab);               // all lanes (expf shuffles its table)
-            else hval = (lane_a || lane_b) ? geglu(gate, up) : 0.0f;
-            const int row_a = pass * R::RB + wave * R::RW + lane / L, row_b = p1 * R::RB + wave * R::RW + lane / L;
+            else hval = (lane_a || lane_b || lane_c) ? geglu(gate, up) : 0.0f;
+            const int row_a = pass * R::RB + wave * R::RW + lane / L, row_b = p1 * R::RB + wave * R::RW + lane / L, row_c = p2 * R::RB + wave * R::RW + lane / L;
             if (lane_a && row_a < o) a.out[row_a >> 1] = hval;
             if (lane_b && row_b < o) a.out[row_b >> 1] = hval;
+            if (lane_c && row_c < o) a.out[row_c >> 1] = hval;
+#ifndef LMRS_GLU_PAIRS
+            if (!have3) break;
+            pass = p3;
+#else
             if (!have2) break;
             pass = p2;
+#endif
         }
     } else
     // double-buffered passes
@@ -949,7 +980,7 @@ __global__ __launch_bounds__(NTH) void gemv_static_kernel(LMRS_HOT_PARAMS, const
     /* Q8_0, dim 2048 / hidden 8192: Llama-3.2-1B */                                                                    \
     X(2048, 32, PRO_RMS_QUANT, EPI_QKV, 256, false) X(2048, 32, PRO_QUANT, EPI_RESID, 256, false) X(2048, 16, PRO_RMS_QUANT, EPI_SWIGLU, 256, false) \
     X(2048, 8, PRO_RMS_QUANT, EPI_CLS, 256, false) X(2048, 32, PRO_PREQ, EPI_STORE, 256, false) X(2048, 8, PRO_PREQ, EPI_STORE, 256, false) \
-    X(8192, 64, PRO_QUANT, EPI_RESID, 512, false) X(8192, 32, PRO_PREQ, EPI_STORE, 256, false) \
+    X(8192, 64, PRO_QUANT, EPI_RESID, 512, false) X(8192, 32, PRO_QUANT, EPI_RESID, 256, false) X(8192, 32, PRO_PREQ, EPI_STORE, 256, false) \
     /* row-sharded step: the activation arrives quantised from the shards that produced it */                         \
     X(2048, 32, PRO_PREQ, EPI_RESID, 256, false) X(8192, 32, PRO_PREQ, EPI_RESID, 256, false) X(3072, 32, PRO_PREQ, EPI_RESID, 256, false) \
     /* Q8_0, dim 3072: Llama-3.2-3B, Phi-3.5 */                                                                         \
@@ -981,7 +1012,11 @@ static StaticClass static_class(const GemvArgs& a, int pro, int epi) {
         if (a.n == 2048) L = glu ? 16 : (a.o >= 8192 ? 8 : 32);
         else if (a.n == 3072) L = a.o >= 8192 ? 16 : 32;
         else if (a.n == 2304) L = epi == EPI_CLS ? 8 : 16;
-        else if (a.n == 8192) { if (pro == PRO_QUANT) { L = 64; nt = 512; } else L = 32; }
+        else if (a.n == 8192) {
+            // (LMRS_W2_L32=1, A/B switch: 32 lanes per row and 256 threads - half the waves to dispatch, twice the prologue per lane)
+            static const int w2_l32 = env_flag("LMRS_W2_L32", 0);
+            if (pro == PRO_QUANT && !w2_l32) { L = 64; nt = 512; } else L = 32;
+        }
         else if (a.n == 9216) { L = 64; nt = 512; }
     } else {
         if (a.n == 2304) L = 8;

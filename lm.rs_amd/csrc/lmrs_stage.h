@@ -57,11 +57,30 @@ template <bool COH> __device__ __forceinline__ float4 ld_f32x4(const float* p) {
 // (32 consecutive lanes own one 128-element quantisation group).
 // ------------------------------------------------------------------------------------------------
 // NTH = threads per workgroup (256 or 512): more threads shorten the per-lane share of the prologue.
+// Grouped passes (round 4): the first NPG = 2, 4 or 8 whole passes are laid out so that a lane's NPG float4s come from ONE 128-element
+// quantisation group - LG = 32 / NPG consecutive lanes own a group, lane l of the cluster the elements 4l .. 4l+3 of each of the group's
+// NPG slices of 4 LG elements (a load instruction still reads whole 128-byte lines: 8 lanes x 16 B at NPG = 4, 16 x 16 B at NPG = 2).
+// The quantiser then needs one group maximum, one scale and one exactness check per LANE instead of one per lane and pass: w2's prologue
+// (8192 values, 512 threads, NPG = 4) went from 245 to 107 vector instructions per wave.  Passes beyond NPG (3072 = 2 + 1, the ragged
+// tails of 2304 and 9216) keep the linear layout, 32 lanes per group.  Element order in LDS / memory is unchanged.
 template <int N, int NTH = kBlk> struct VecGeom {
     static constexpr int PER = NTH * 4;                       // elements per pass over the workgroup
     static constexpr int NP = (N + PER - 1) / PER;
     static constexpr bool FULL = (N % PER) == 0;
     static constexpr int G = N / 128;
+#ifndef LMRS_NO_GROUPED
+    static constexpr int NPG = N / PER >= 8 ? 8 : N / PER >= 4 ? 4 : N / PER >= 2 ? 2 : 0;     // grouped passes
+#else
+    static constexpr int NPG = 0;
+#endif
+    static constexpr int LG = NPG ? 32 / NPG : 32;            // lanes that own one quantisation group of the grouped passes
+    // first element of thread t's float4 number i (i: a constant after unrolling)
+    __device__ static __forceinline__ int elem(int i, int t) {
+        if (i < NPG) return (t / LG) * 128 + i * (LG * 4) + (t % LG) * 4;
+        return i * PER + t * 4;
+    }
+    // is float4 number i of thread t inside the vector (only the last pass of a ragged vector can be outside)
+    __device__ static __forceinline__ bool live(int i, int t) { return FULL || i < NP - 1 || i * PER + t * 4 < N; }
 };
 
 template <int N, bool COH, int NTH = kBlk>
@@ -69,10 +88,10 @@ __device__ __forceinline__ void vec_load(float4 (&v)[(VecGeom<N, NTH>::NP)], con
     constexpr int NP = VecGeom<N, NTH>::NP;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = i * VecGeom<N, NTH>::PER + (int)threadIdx.x * 4;
+        const int e = VecGeom<N, NTH>::elem(i, (int)threadIdx.x);
         if constexpr (VecGeom<N, NTH>::FULL) v[i] = ld_f32x4<COH>(x + e);
         else if (i < NP - 1) v[i] = ld_f32x4<COH>(x + e);
-        else {
+        else {                                                     // (the ragged pass is never a grouped one: NPG <= N / PER)
             // ragged last pass (N = 2304, 9216): the load stays UNCONDITIONAL on a clamped address and the lanes past the end are
             // zeroed by a select - a load under a lane predicate makes hipcc wait for ALL outstanding loads (vmcnt(0)) right there,
             // i.e. before the weight tile is even requested (measured: x landed at 2.9 us instead of 0.7 in the Gemma prologues)
@@ -109,7 +128,7 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = i * VecGeom<N, NTH>::PER + t * 4;
+        const int e = VecGeom<N, NTH>::elem(i, t);
         if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) {
             const int j = e >> 3, k0 = e & 7;
             scratch[(k0 + 0) * JP + j] = v[i].x * v[i].x;
@@ -158,12 +177,23 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
                 for (int u = 0; u < BF; ++u) rms_chain8(p, B[u]);
             }
         }
+#ifndef LMRS_SHFL_RMS_TAIL
+        // lanes 0..7 hold the chains' sums: v_readlane_b32 (no LDS crossbar round trip as with __shfl); every lane then computes the same scalar
+        const int pi = __float_as_int(p);                    // (the builtin is int -> int: a float argument would be CONVERTED)
+        const float p0 = __int_as_float(__builtin_amdgcn_readlane(pi, 0)), p1 = __int_as_float(__builtin_amdgcn_readlane(pi, 1));
+        const float p2 = __int_as_float(__builtin_amdgcn_readlane(pi, 2)), p3 = __int_as_float(__builtin_amdgcn_readlane(pi, 3));
+        const float p4 = __int_as_float(__builtin_amdgcn_readlane(pi, 4)), p5 = __int_as_float(__builtin_amdgcn_readlane(pi, 5));
+        const float p6 = __int_as_float(__builtin_amdgcn_readlane(pi, 6)), p7 = __int_as_float(__builtin_amdgcn_readlane(pi, 7));
+#else
         const int wl = t & 48;                               // lanes 0..7 of this lane's own row hold the chains' sums
         const float p0 = __shfl(p, wl + 0), p1 = __shfl(p, wl + 1), p2 = __shfl(p, wl + 2), p3 = __shfl(p, wl + 3);
         const float p4 = __shfl(p, wl + 4), p5 = __shfl(p, wl + 5), p6 = __shfl(p, wl + 6), p7 = __shfl(p, wl + 7);
+#endif
         if ((t & 63) == 0) {
             float ss = reduce_add8(p0, p1, p2, p3, p4, p5, p6, p7);
-            ss = ss / (float)N;
+            // (N a power of two: the quotient and the product by 2^-k are the same real number, rounded once either way - no division sequence)
+            if constexpr ((N & (N - 1)) == 0) ss = ss * (1.0f / (float)N);
+            else ss = ss / (float)N;
             ss = ss + eps;
             ss = 1.0f / sqrtf(ss);
             scratch[8 * JP] = ss;
@@ -187,55 +217,80 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
 }
 
 // quantize (reference quantization.rs:44-67) of v[] into LDS: xq[N] int8, xs[N/128] f32.
+// Every workgroup of a launch quantises the SAME vector, so whatever one wave does here is on the critical path of the launch - the
+// exact redo of candidates near a rounding boundary included.  It is kept small: per pass, and inside a pass only the elements some
+// lane flagged (usually one; round 3 redid the four elements of every lane of the pass, ~100 instructions, on 4 launches out of 5).
 template <int N, int NTH = kBlk, class F = NoHook>
 __device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NTH>::NP)], int8_t* xq, float* xs, unsigned long long* dbg = nullptr, F landed = F()) {
-    constexpr int NP = VecGeom<N, NTH>::NP;
+    using V = VecGeom<N, NTH>;
+    constexpr int NP = V::NP, NPG = V::NPG, NL = NP - NPG;         // grouped passes [0, NPG), linear passes [NPG, NP)
     const int t = threadIdx.x;
-    // three flat phases (all passes' group maxima, then all scales, then all elements) so that the independent
-    // cross-lane reductions / divisions of the passes overlap instead of running one pass after the other
-    float m[NP];
+    // flat phases (all maxima, then all scales, then all candidates) so that the independent cross-lane reductions of the
+    // grouped part and of every linear pass overlap instead of running one after the other
+    float mg = 0.0f, ml[NL ? NL : 1];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int e = i * VecGeom<N, NTH>::PER + t * 4;
-        const bool live = VecGeom<N, NTH>::FULL || i < NP - 1 || e < N;
-        m[i] = live ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.0f;
-    }
+    for (int i = 0; i < NPG; ++i) mg = absmax4(v[i], mg);          // the lane's NPG float4s belong to one group
+#pragma unroll
+    for (int i = NPG; i < NP; ++i) ml[i - NPG] = V::live(i, t) ? absmax4(v[i], 0.0f) : 0.0f;
     landed();                                                     // the activation has arrived in this wave
+    if constexpr (NPG > 0) mg = cluster_max<V::LG>(mg);           // wmax of each 128-group (max is order-free)
 #pragma unroll
-    for (int i = 0; i < NP; ++i) m[i] = group32_max(m[i]);        // wmax of each 128-group (max is order-free)
+    for (int i = 0; i < NL; ++i) ml[i] = group32_max(ml[i]);
     if (dbg && t == 0) dbg[6] = wall_clock64();
-    float sc[NP], inv[NP];
+    // scale: stored, must be the IEEE quotient (div127_sane); inv: 1 ulp suffices (quant_q8_cand)
+    float scg = div127_sane(mg), scl[NL ? NL : 1];
+    const float invg = __builtin_amdgcn_rcpf(scg);
+    float invl[NL ? NL : 1];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { sc[i] = m[i] / 127.0f; inv[i] = __builtin_amdgcn_rcpf(sc[i]); }   // scale: IEEE division (it is stored); inv: 1 ulp suffices
+    for (int i = 0; i < NL; ++i) { scl[i] = div127_sane(ml[i]); invl[i] = __builtin_amdgcn_rcpf(scl[i]); }
     // (Round 4, measured and removed: candidates by magic-number add - t = x * inv + 1.5 * 2^23 leaves rint(x * inv) in t's low byte, packed
     // v_pk_mul_f32 / v_pk_add_f32, no rint, no convert; 0 mismatches in 6e8 cases (quant_check), bit-equal on the GPU, and 419 -> 422 us
     // per step: a packed f32 instruction issues in twice the time of a scalar-per-lane one on this chip, the count halved buys nothing.)
-    // all candidates first (branch-free, so the passes interleave), then the rare exact redo, one branch per pass
     int q[NP][4];
+    float4 d[NP];
     float dev[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        dev[i] = 0.0f;
-        q[i][0] = quant_q8_try(v[i].x, inv[i], dev[i]); q[i][1] = quant_q8_try(v[i].y, inv[i], dev[i]);
-        q[i][2] = quant_q8_try(v[i].z, inv[i], dev[i]); q[i][3] = quant_q8_try(v[i].w, inv[i], dev[i]);
+        const float inv = i < NPG ? invg : invl[i < NPG ? 0 : i - NPG];
+        q[i][0] = quant_q8_cand(v[i].x, inv, d[i].x); q[i][1] = quant_q8_cand(v[i].y, inv, d[i].y);
+        q[i][2] = quant_q8_cand(v[i].z, inv, d[i].z); q[i][3] = quant_q8_cand(v[i].w, inv, d[i].w);
+        dev[i] = absmax4(d[i], 0.0f);
+    }
+    // groups whose maximum is zero / denormal / huge / NaN: the division, then every element the reference's way.  (Wave-uniform branch,
+    // operand behind an opaque asm: as a plain select hipcc hoists the division sequence onto the fast path.)
+    const bool insane_g = NPG > 0 && !quant_group_sane(mg);
+    bool insane_l[NL ? NL : 1];
+    bool any_insane = insane_g;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { insane_l[i] = !quant_group_sane(ml[i]); any_insane = any_insane || insane_l[i]; }
+    if (__any(any_insane)) {
+        float mm = mg; asm volatile("" : "+v"(mm));
+        if (insane_g) scg = mm / 127.0f;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { float ml2 = ml[i]; asm volatile("" : "+v"(ml2)); if (insane_l[i]) scl[i] = ml2 / 127.0f; }
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        if (quant_slow(m[i], dev[i])) {
-            q[i][0] = quant_q8(v[i].x, sc[i]); q[i][1] = quant_q8(v[i].y, sc[i]);
-            q[i][2] = quant_q8(v[i].z, sc[i]); q[i][3] = quant_q8(v[i].w, sc[i]);
+        const bool insane = i < NPG ? insane_g : insane_l[i < NPG ? 0 : i - NPG];
+        const float sc = i < NPG ? scg : scl[i < NPG ? 0 : i - NPG];
+        if (insane || dev[i] > kQuantDevMax) {
+            if (__any(insane || fabsf(d[i].x) > kQuantDevMax)) q[i][0] = quant_q8(v[i].x, sc);
+            if (__any(insane || fabsf(d[i].y) > kQuantDevMax)) q[i][1] = quant_q8(v[i].y, sc);
+            if (__any(insane || fabsf(d[i].z) > kQuantDevMax)) q[i][2] = quant_q8(v[i].z, sc);
+            if (__any(insane || fabsf(d[i].w) > kQuantDevMax)) q[i][3] = quant_q8(v[i].w, sc);
         }
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = i * VecGeom<N, NTH>::PER + t * 4;
-        if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) {
+        if (V::live(i, t)) {
+            const int e = V::elem(i, t);
             const unsigned lo = __builtin_amdgcn_perm((unsigned)q[i][1], (unsigned)q[i][0], 0x0c0c0400u);
             const unsigned hi = __builtin_amdgcn_perm((unsigned)q[i][3], (unsigned)q[i][2], 0x0c0c0400u);
             *reinterpret_cast<unsigned*>(xq + e) = lo | (hi << 16);
-            if ((t & 31) == 0) xs[e >> 7] = sc[i];
+            if (i >= NPG && (t & 31) == 0) xs[e >> 7] = scl[i < NPG ? 0 : i - NPG];
         }
     }
+    if (NPG > 0 && (t % V::LG) == 0) xs[t / V::LG] = scg;
 }
 
 // quantize_q4 (reference quantization.rs:69-95) of v[] into LDS: xq4[N/2] packed nibbles, xs[N/128] f32.
@@ -243,49 +298,57 @@ __device__ __forceinline__ void vec_quantize_q8(const float4 (&v)[(VecGeom<N, NT
 // value the reference multiplies (functional.rs:236-240), is the 4-bit two's-complement number with exactly that bit
 // pattern, so v_dot8_i32_i4 on (weights ^ 0x88888888, this) is the group's integer sum with no unpacking at all.
 // Candidates without the per-element division as in vec_quantize_q8: n = rint(x * inv + 8.0); lanes whose value lies
-// within 1e-4 of a rounding boundary, and abnormal groups, redo the reference arithmetic (quant_q4_try, lmrs_device_math.h).
+// within 4e-5 of a rounding boundary, and abnormal groups, redo the reference arithmetic (quant_q4_cand, lmrs_device_math.h).
 template <int N, int NTH = kBlk, class F = NoHook>
 __device__ __forceinline__ void vec_quantize_q4(const float4 (&v)[(VecGeom<N, NTH>::NP)], int8_t* xq4, float* xs, unsigned long long* dbg = nullptr, F landed = F()) {
-    constexpr int NP = VecGeom<N, NTH>::NP;
+    using V = VecGeom<N, NTH>;
+    constexpr int NP = V::NP, NPG = V::NPG, NL = NP - NPG;
     const int t = threadIdx.x;
-    float m[NP];
+    float mg = 0.0f, ml[NL ? NL : 1];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int e = i * VecGeom<N, NTH>::PER + t * 4;
-        const bool live = VecGeom<N, NTH>::FULL || i < NP - 1 || e < N;
-        m[i] = live ? fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))) : 0.0f;
-    }
+    for (int i = 0; i < NPG; ++i) mg = absmax4(v[i], mg);
+#pragma unroll
+    for (int i = NPG; i < NP; ++i) ml[i - NPG] = V::live(i, t) ? absmax4(v[i], 0.0f) : 0.0f;
     landed();
+    if constexpr (NPG > 0) mg = cluster_max<V::LG>(mg);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) m[i] = group32_max(m[i]);
+    for (int i = 0; i < NL; ++i) ml[i] = group32_max(ml[i]);
     if (dbg && t == 0) dbg[6] = wall_clock64();
-    float sc[NP], inv[NP];
+    const float scg = mg / -8.0f, invg = __builtin_amdgcn_rcpf(scg);      // (a power of two: hipcc multiplies)
+    float scl[NL ? NL : 1], invl[NL ? NL : 1];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { sc[i] = m[i] / -8.0f; inv[i] = __builtin_amdgcn_rcpf(sc[i]); }
+    for (int i = 0; i < NL; ++i) { scl[i] = ml[i] / -8.0f; invl[i] = __builtin_amdgcn_rcpf(scl[i]); }
     unsigned q[NP][4];
+    float4 d[NP];
     float dev[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        dev[i] = 0.0f;
-        q[i][0] = quant_q4_try(v[i].x, inv[i], dev[i]); q[i][1] = quant_q4_try(v[i].y, inv[i], dev[i]);
-        q[i][2] = quant_q4_try(v[i].z, inv[i], dev[i]); q[i][3] = quant_q4_try(v[i].w, inv[i], dev[i]);
+        const float inv = i < NPG ? invg : invl[i < NPG ? 0 : i - NPG];
+        q[i][0] = quant_q4_cand(v[i].x, inv, d[i].x); q[i][1] = quant_q4_cand(v[i].y, inv, d[i].y);
+        q[i][2] = quant_q4_cand(v[i].z, inv, d[i].z); q[i][3] = quant_q4_cand(v[i].w, inv, d[i].w);
+        dev[i] = absmax4(d[i], 0.0f);
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        if (quant_slow(m[i], dev[i])) {
-            q[i][0] = quant_q4(v[i].x, sc[i]); q[i][1] = quant_q4(v[i].y, sc[i]);
-            q[i][2] = quant_q4(v[i].z, sc[i]); q[i][3] = quant_q4(v[i].w, sc[i]);
+        const float m = i < NPG ? mg : ml[i < NPG ? 0 : i - NPG], sc = i < NPG ? scg : scl[i < NPG ? 0 : i - NPG];
+        const bool insane = !quant_group_sane(m);
+        if (insane || dev[i] > kQuantDevMax) {
+            if (__any(insane || fabsf(d[i].x) > kQuantDevMax)) q[i][0] = quant_q4(v[i].x, sc);
+            if (__any(insane || fabsf(d[i].y) > kQuantDevMax)) q[i][1] = quant_q4(v[i].y, sc);
+            if (__any(insane || fabsf(d[i].z) > kQuantDevMax)) q[i][2] = quant_q4(v[i].z, sc);
+            if (__any(insane || fabsf(d[i].w) > kQuantDevMax)) q[i][3] = quant_q4(v[i].w, sc);
         }
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = i * VecGeom<N, NTH>::PER + t * 4;
-        if (VecGeom<N, NTH>::FULL || i < NP - 1 || e < N) {
+        if (V::live(i, t)) {
+            const int e = V::elem(i, t);
             const unsigned packed = (q[i][0] | (q[i][1] << 4) | (q[i][2] << 8) | (q[i][3] << 12)) ^ 0x8888u;
             *reinterpret_cast<unsigned short*>(xq4 + (e >> 1)) = (unsigned short)packed;
-            if ((t & 31) == 0) xs[e >> 7] = sc[i];
+            if (i >= NPG && (t & 31) == 0) xs[e >> 7] = scl[i < NPG ? 0 : i - NPG];
         }
     }
+    if (NPG > 0 && (t % V::LG) == 0) xs[t / V::LG] = scg;
 }
 
 // ------------------------------------------------------------------------------------------------

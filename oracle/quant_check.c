@@ -4,7 +4,8 @@
  * q = (x / scale).round() as i8  (reference src/quantization.rs:62-63) on random and adversarial inputs.
  * The fast path multiplies by 1/scale and falls back to the exact IEEE division whenever the product lies
  * within 1e-4 of a rounding boundary (k + 0.5), which covers the worst-case error of the product (3.1e-5 with a 1-ulp reciprocal), or the
- * group maximum is not a normal number in [1e-30, 1e30].  |x| <= wmax as in a real group (x is an element of it).
+ * group maximum is not a normal number in [1e-30, 1e30].  (Round 4: the window is 4e-5 - kQuantDevMax = 0.49996 - still above the 3.1e-5 bound.)
+ * Also checks, exhaustively, the division-free group scale m / 127 (div127_sane).  |x| <= wmax as in a real group (x is an element of it).
  *   usage: ./quant_check        (prints the number of mismatches: must be 0)
  */
 #include <math.h>
@@ -25,7 +26,7 @@ static inline int fast_q(float x, float inv, float scale, float wmax) {
     int slow = !(wmax > 1.0e-30f && wmax < 1.0e30f);
     const float r = x * inv;
     const float n = rintf(r);
-    slow |= fabsf(r - n) > 0.4999f;
+    slow |= fabsf(r - n) > 0.49996f;
     if (slow) return exact_q(x, scale);
     return (int)n;      /* v_cvt_i32_f32; |n| <= 127 here, asserted below */
 }
@@ -41,7 +42,7 @@ static inline unsigned fast_q4(float x, float inv, float scale, float wmax) {
     int slow = !(wmax > 1.0e-30f && wmax < 1.0e30f);
     const float s = x * inv + 8.0f;
     const float n = rintf(s);
-    slow |= fabsf(s - n) > 0.4999f;
+    slow |= fabsf(s - n) > 0.49996f;
     if (slow) return exact_q4(x, scale);
     const unsigned q = (unsigned)(int)n;
     return q < 15u ? q : 15u;
@@ -94,6 +95,22 @@ int main(void) {
     for (unsigned i = 0; i < sizeof zs / sizeof *zs; ++i)
         for (unsigned j = 0; j < sizeof zs / sizeof *zs; ++j) { if (exact_q(zs[j], zs[i] / 127.0f) != fast_q(zs[j], 1.0f / (zs[i] / 127.0f), zs[i] / 127.0f, zs[i])) bad++; n++;
               if (exact_q4(zs[j], zs[i] / -8.0f) != fast_q4(zs[j], 1.0f / (zs[i] / -8.0f), zs[i] / -8.0f, zs[i])) bad++; n++; }
+    /* the scale without the division sequence (lmrs_stage.h div127_sane): y = RN(1/127), q0 = m y, r = fma(-127, q0, m), q = fma(r, y, q0)
+     * against m / 127.0f for EVERY float of the range quant_group_sane admits (and 16 neighbours either side) */
+    {
+        const float y = 0x1.020408p-7f, lo_f = 1.0e-30f, hi_f = 1.0e30f;
+        uint32_t lo, hi; memcpy(&lo, &lo_f, 4); memcpy(&hi, &hi_f, 4);
+        unsigned long long dbad = 0;
+        for (uint32_t b = lo - 16; b <= hi + 16; ++b) {
+            float m; memcpy(&m, &b, 4);
+            const float q0 = m * y;
+            const float r = fmaf(-127.0f, q0, m);
+            const float q = fmaf(r, y, q0), e = m / 127.0f;
+            if (memcmp(&q, &e, 4)) dbad++;
+        }
+        printf("div127: %u cases, %llu mismatches\n", hi - lo + 33, dbad);
+        bad += dbad;
+    }
     printf("cases: %llu  mismatches: %llu\n", n, bad);
     return bad != 0;
 }

@@ -2449,28 +2449,28 @@ __global__ __launch_bounds__(kBlock) void quantize_kernel(const float* x, void* 
     quantize_to_lds<Q4, kMaxP>(v, n, xq, xs, q, s);
 }
 
-// The static kernels' quantiser (vec_quantize_q8) behind the same entry point, for the shapes they are built for.
-template <int N, int NTH>
+// The static kernels' quantisers (vec_quantize_q8 / vec_quantize_q4: the prologue code of the decode launches, grouped passes and the
+// ragged Gemma lengths included) behind the same entry point, for the shapes they are built for.
+template <int N, int NTH, bool Q4>
 __global__ __launch_bounds__(NTH) void quantize_static_kernel(const float* x, int8_t* q, float* s) {
     __shared__ __attribute__((aligned(16))) int8_t xq[N];
     __shared__ float xs[N / 128];
     float4 v[(VecGeom<N, NTH>::NP)];
     vec_load<N, false, NTH>(v, x);
-    vec_quantize_q8<N, NTH>(v, xq, xs);
+    if constexpr (Q4) vec_quantize_q4<N, NTH>(v, xq, xs); else vec_quantize_q8<N, NTH>(v, xq, xs);
     lds_barrier();
-    for (int e = threadIdx.x * 4; e < N; e += NTH * 4) *reinterpret_cast<unsigned*>(q + e) = *reinterpret_cast<const unsigned*>(xq + e);
+    // Q4_0: the LDS image holds every nibble XOR 8 (lmrs_stage.h); the reference's packing is the plain nibbles
+    for (int e = threadIdx.x * 4; e < (Q4 ? N / 2 : N); e += NTH * 4) *reinterpret_cast<unsigned*>(q + e) = *reinterpret_cast<const unsigned*>(xq + e) ^ (Q4 ? 0x88888888u : 0u);
     for (int g = threadIdx.x; g < N / 128; g += NTH) s[g] = xs[g];
 }
 
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st) {
     if (n % kGS || n > kMaxP * 1024) return hipErrorInvalidValue;
-    if (!q4 && (n == 2048 || n == 3072 || n == 8192)) {
-        int8_t* q8 = static_cast<int8_t*>(q);
-        if (n == 2048) LMRS_LAUNCH_GRID((quantize_static_kernel<2048, 256>), dim3(1), 256, 0, st, x, q8, s);
-        else if (n == 3072) LMRS_LAUNCH_GRID((quantize_static_kernel<3072, 256>), dim3(1), 256, 0, st, x, q8, s);
-        else LMRS_LAUNCH_GRID((quantize_static_kernel<8192, 512>), dim3(1), 512, 0, st, x, q8, s);
-        return hipGetLastError();
-    }
+    int8_t* q8 = static_cast<int8_t*>(q);
+#define QS(N_, NT_) if (n == N_) { if (q4) LMRS_LAUNCH_GRID((quantize_static_kernel<N_, NT_, true>), dim3(1), NT_, 0, st, x, q8, s); \
+                                   else LMRS_LAUNCH_GRID((quantize_static_kernel<N_, NT_, false>), dim3(1), NT_, 0, st, x, q8, s); return hipGetLastError(); }
+    QS(2048, 256) QS(3072, 256) QS(8192, 512) QS(2304, 256) QS(9216, 512)
+#undef QS
     const size_t smem = ((n + 15) & ~15) + (size_t)(n / kGS + 4) * 4;
     if (q4) LMRS_LAUNCH_GRID(quantize_kernel<true>, dim3(1), kBlock, smem, st, x, q, s, n);
     else LMRS_LAUNCH_GRID(quantize_kernel<false>, dim3(1), kBlock, smem, st, x, q, s, n);

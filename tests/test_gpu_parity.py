@@ -133,7 +133,7 @@ def test_quantize(L, n):
     assert_bit_equal(s4, s4o, "q4 scales"); assert (q4 == q4o).all()
 
 
-@pytest.mark.parametrize("n", [2048, 8192, 2304])
+@pytest.mark.parametrize("n", [2048, 3072, 8192, 2304, 9216, 1024])
 def test_quantize_adversarial_rounding_boundaries(L, n):
     """The device quantiser multiplies by 1/scale and redoes the exact division only near a rounding boundary:
     inputs sitting exactly on / a few ulp around (k + 0.5) * scale, plus degenerate groups (zero, denormal, huge,
@@ -159,6 +159,34 @@ def test_quantize_adversarial_rounding_boundaries(L, n):
     q, s = L.quantize(x)
     qo, so = O.quantize(x)
     assert_bit_equal(s, so, "q8 scales"); assert (q == qo).all()
+
+
+@pytest.mark.parametrize("n", [2048, 3072, 8192, 2304, 9216, 1024])
+def test_quantize_q4_adversarial_rounding_boundaries(L, n):
+    """The same for quantize_q4 (quantization.rs:69-95: nibble = clamp(round(x / scale + 8), 0, 15), scale = wmax / -8): inputs on / a few
+    ulp around the boundaries k + 0.5, degenerate groups, through the static prologue quantiser of every decode shape (grouped passes at
+    2048 / 8192, grouped + linear at 3072, grouped + ragged at 2304 / 9216) and the generic kernel (1024)."""
+    rng = np.random.default_rng(70 + n)
+    x = np.empty(n, np.float32)
+    for g in range(n // 128):
+        wmax = np.float32(np.ldexp(0.5 + rng.random(), int(rng.integers(-20, 10))))
+        sc = np.float32(wmax / np.float32(-8.0))
+        k = rng.integers(0, 16, 128).astype(np.float32)
+        v = ((k + np.float32(0.5) - np.float32(8.0)) * sc).astype(np.float32)
+        u = v.view(np.uint32) + rng.integers(-4, 5, 128).astype(np.int64)
+        v = u.astype(np.uint32).view(np.float32)
+        v[int(rng.integers(0, 128))] = wmax * rng.choice(np.array([-1.0, 1.0], np.float32))
+        x[g * 128:(g + 1) * 128] = np.clip(v, -wmax, wmax)
+    specials = [np.float32(0.0), np.float32(1e-42), np.float32(3e-39), np.float32(2e-38), np.float32(3e38), np.float32(np.inf), np.float32(np.nan)]
+    for i, sp in enumerate(specials):
+        if i + 1 < n // 128:
+            grp = (rng.standard_normal(128) * 1e-3).astype(np.float32) if np.isfinite(sp) and sp != 0 else np.zeros(128, np.float32)
+            grp = np.clip(grp, -abs(sp), abs(sp)) if np.isfinite(sp) else grp
+            grp[3] = sp
+            x[(i + 1) * 128:(i + 2) * 128] = grp
+    q4, s4 = L.quantize_q4(x)
+    q4o, s4o = O.quantize_q4(x)
+    assert_bit_equal(s4, s4o, "q4 scales"); assert (q4 == q4o).all()
 
 
 @pytest.mark.parametrize("n,unit", [(128, False), (2048, False), (2304, True), (3072, False), (4096, True)])

@@ -120,6 +120,17 @@ __device__ __forceinline__ void rms_chain8(float& p, const float4& a) {
                  "v_add_f32_dpp %0, %4, %0 row_shl:8 row_mask:0xf bank_mask:0xf"
                  : "+v"(p) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
 }
+// four batches as ONE asm block: between separate asm statements hipcc inserts an s_nop (it cannot see what the block reads), and an
+// s_nop costs the chain a whole 4-cycle issue slot like an add (tools/ubench/addlat.hip)
+#define LMRS_RMS8(a, b, c, d) "v_add_f32 %0, %0, %" #a "\n\tv_add_f32 %0, %0, %" #b "\n\tv_add_f32 %0, %0, %" #c "\n\tv_add_f32 %0, %0, %" #d "\n\t" \
+    "v_add_f32_dpp %0, %" #a ", %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %" #b ", %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_f32_dpp %0, %" #c ", %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %0, %" #d ", %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void rms_chain32(float& p, const float4 (&a)[4]) {
+    asm volatile(LMRS_RMS8(1, 2, 3, 4) LMRS_RMS8(5, 6, 7, 8) LMRS_RMS8(9, 10, 11, 12) LMRS_RMS8(13, 14, 15, 16)
+                 : "+v"(p)
+                 : "v"(a[0].x), "v"(a[0].y), "v"(a[0].z), "v"(a[0].w), "v"(a[1].x), "v"(a[1].y), "v"(a[1].z), "v"(a[1].w),
+                   "v"(a[2].x), "v"(a[2].y), "v"(a[2].z), "v"(a[2].w), "v"(a[3].x), "v"(a[3].y), "v"(a[3].z), "v"(a[3].w));
+}
 template <int N, int NTH = kBlk, class F = NoHook>
 __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], const float4 (&nw)[(VecGeom<N, NTH>::NP)], float eps, int add_unit, float* scratch,
                                             unsigned long long* dbg = nullptr, F landed = F(), const int chain_wave = 0) {
@@ -165,16 +176,14 @@ __device__ __forceinline__ void vec_rmsnorm(float4 (&v)[(VecGeom<N, NTH>::NP)], 
                 for (int u = 0; u < BF; ++u) B[u] = row[2 * ((b0 + 1) * BF + u)];
             }
             asm volatile("" ::: "memory");                       // the reads above are issued before the adds below
-#pragma unroll
-            for (int u = 0; u < BF; ++u) rms_chain8(p, A[u]);
+            rms_chain32(p, A);
             if (b0 + 1 < NB) {
                 if (b0 + 2 < NB) {
 #pragma unroll
                     for (int u = 0; u < BF; ++u) A[u] = row[2 * ((b0 + 2) * BF + u)];
                 }
                 asm volatile("" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < BF; ++u) rms_chain8(p, B[u]);
+                rms_chain32(p, B);
             }
         }
 #ifndef LMRS_SHFL_RMS_TAIL

@@ -475,11 +475,38 @@ def main():
         # RCCL all-gathers over xGMI.  The library's OWN choice for this model and world size (for the small models plan "cls" over the
         # peer-to-peer push transport) is measured in the same job and rides along as `library_choice`, so that one
         # run yields both (LMRS_BENCH_SINGLE_PLAN=1 / LMRS_SHARD_PLAN=...: one configuration only).
-        lib_out = run_once(emit=False)
-        barrier()
+        # Order and guard (round 4): the headline configuration runs FIRST and its line is held; the library's own choice - whose default
+        # transport, the peer-to-peer push over xGMI, has never crossed a real link - then runs under a watchdog on every rank.  If it
+        # raises, hangs or kills a peer, rank 0 still prints the headline line (with `library_choice` saying why it is missing) and every
+        # rank leaves: a driver on a real node always gets its one JSON line.
+        import threading
         one_dev = os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1"                      # (RCCL refuses two ranks on one device)
         out = run_once(plan="tp", transport_override=None if one_dev else "rccl", emit=False)
-        if rank == 0:
+        barrier()
+        printed = threading.Lock()
+
+        def emit_and_leave(why):
+            if not printed.acquire(blocking=False):
+                return
+            if rank == 0:
+                out["library_choice"] = {"value": None, "skipped": why}
+                print(json.dumps(out), flush=True)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)                                   # (collectives of the abandoned run may never return: no orderly teardown)
+
+        limit = float(os.environ.get("LMRS_BENCH_LIBRARY_CHOICE_TIMEOUT", "240"))
+        dog = threading.Timer(limit, emit_and_leave, args=(f"the library-choice run did not finish within {limit:.0f} s",))
+        dog.daemon = True; dog.start()
+        os.environ.pop("LMRS_SHARD_PLAN", None)            # (run_once(plan=...) set it for the headline run)
+        try:
+            lib_out = run_once(emit=False)
+            barrier()
+        except BaseException as e:                          # noqa: BLE001 - the headline line must get out whatever happened here
+            print(f"[rank {rank}] library-choice run failed: {type(e).__name__}: {e}", file=sys.stderr)
+            emit_and_leave(f"the library-choice run failed on a rank: {type(e).__name__}")
+            time.sleep(limit)                               # (another thread is printing: wait for its exit)
+        dog.cancel()
+        if printed.acquire(blocking=False) and rank == 0:
             out["library_choice"] = {k: lib_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
             out["library_choice"]["parallelism"] = lib_out["config"]["parallelism"]
             out["library_choice"]["roofline"] = {k: lib_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}

@@ -54,12 +54,12 @@ def exchange_unique_id(dist, rank, make_id):
 
 
 def kernel_source_hash():
-    """Identifies the build of the kernels: sha256 over the sources liblmrs_hip.so is made from."""
+    """Identifies the build of the kernels: sha256 over the sources liblmrs_hip.so is made from and the Makefile that carries its flags."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "lm.rs_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".inc", ".h", ".cpp")):
+        if f.endswith((".hip", ".inc", ".h", ".cpp")) or f == "Makefile":
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

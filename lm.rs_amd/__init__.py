@@ -46,7 +46,7 @@ class TransformerArgs(C.Structure):
 def build(force: bool = False) -> str:
     """Compile liblmrs_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", ".inc"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "lmrs_hip.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "lmrs_hip.h")); srcs.append(os.path.join(CSRC, "Makefile"))     # (the flags are part of the build)
     def stale():
         return not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale():

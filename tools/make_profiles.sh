@@ -2,14 +2,15 @@
 # Regenerates the round's measurement artefacts on a GPU box (run from the repo root through gpurun); everything lands in
 # gpurun_out/art/ and is copied into profiles/ by hand afterwards.  PMC counters are collected in their own rocprofv3 runs
 # (--kernel-trace only, one counter per pass), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-#   usage: bash tools/make_profiles.sh <tag> [pmc]      (e.g. r4; `pmc`: only the counter passes and the bench lines that quote them)
+#   usage: bash tools/make_profiles.sh <tag> [pmc|lite|extra]   (e.g. r4; `pmc`: only the counter passes and the bench lines that quote them;
+#          `lite`: counters, rocprofv3 kernel statistics and the bench lines of the four models - no timeline / prefill / vision / two-rank runs)
 set -u
 TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 export LMRS_BENCH_IMAGE_CACHE=/tmp          # the synthetic images are built once, outside the profiler
 OUT=gpurun_out/art; ONLY=${2:-all}
-if [ "$ONLY" = all ]; then rm -rf $OUT; fi
+if [ "$ONLY" = all ] || [ "$ONLY" = lite ]; then rm -rf $OUT; fi
 mkdir -p $OUT
 pmc() {   # model qtype out-json
     for c in FETCH_SIZE WRITE_SIZE; do
@@ -55,6 +56,7 @@ timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.js
 timeout 300 python bench.py --model gemma-2-2b --qtype q4_0 --steps 64 > $OUT/${TAG}_bench_gemma2b_q4.json 2>> $OUT/bench.err
 timeout 400 python bench.py --model llama-3.2-3b --steps 64 > $OUT/${TAG}_bench_llama3b.json 2>> $OUT/bench.err
 timeout 400 python bench.py --model phi-3.5 --steps 64 > $OUT/${TAG}_bench_phi35.json 2>> $OUT/bench.err
+if [ "$ONLY" = lite ]; then exit 0; fi          # (`lite`: counters, kernel statistics and the bench lines of the four models only)
 timeout 200 python tools/timeline.py llama-3.2-1b 100 > $OUT/${TAG}_timeline_llama1b.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf -- python tools/prefill_rate.py llama-3.2-1b 512 > $OUT/${TAG}_prefill512.log 2>&1
 cp $(ls $OUT/pf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prefill512_kernel_stats.csv; rm -rf $OUT/pf

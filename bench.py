@@ -125,6 +125,44 @@ def max_over_ranks(dist, seconds, device=None):
     return float(t.item())
 
 
+def headline_then_guarded(headline, second, barrier, rank, limit_s, leave=os._exit):
+    """N > 1: run the headline configuration, hold its line, then run the second configuration under a watchdog on every rank; rank 0
+    prints exactly ONE JSON line whatever the second run does.  second() returning: the line carries `library_choice` with its figures.
+    second() raising on this rank, or not returning within limit_s: the line carries `library_choice: {value: null, skipped: why}` and
+    the process leaves through `leave` (os._exit: the abandoned run's collectives may never return, so no orderly teardown)."""
+    import threading
+    out = headline()
+    barrier()
+    printed = threading.Lock()
+
+    def emit_and_leave(why):
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            out["library_choice"] = {"value": None, "skipped": why}
+            print(json.dumps(out), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        leave(0)
+
+    dog = threading.Timer(limit_s, emit_and_leave, args=(f"the library-choice run did not finish within {limit_s:.0f} s",))
+    dog.daemon = True; dog.start()
+    try:
+        lib_out = second()
+        barrier()
+    except BaseException as e:                              # noqa: BLE001 - the headline line must get out whatever happened here
+        print(f"[rank {rank}] library-choice run failed: {type(e).__name__}: {e}", file=sys.stderr)
+        emit_and_leave(f"the library-choice run failed on a rank: {type(e).__name__}")
+        time.sleep(limit_s)                                 # (the watchdog thread is printing: wait for its exit)
+        return out
+    dog.cancel()
+    if printed.acquire(blocking=False) and rank == 0:
+        out["library_choice"] = {k: lib_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
+        out["library_choice"]["parallelism"] = lib_out["config"]["parallelism"]
+        out["library_choice"]["roofline"] = {k: lib_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}
+        print(json.dumps(out), flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -479,38 +517,16 @@ def main():
         # transport, the peer-to-peer push over xGMI, has never crossed a real link - then runs under a watchdog on every rank.  If it
         # raises, hangs or kills a peer, rank 0 still prints the headline line (with `library_choice` saying why it is missing) and every
         # rank leaves: a driver on a real node always gets its one JSON line.
-        import threading
         one_dev = os.environ.get("LMRS_BENCH_ONE_DEVICE") == "1"                      # (RCCL refuses two ranks on one device)
-        out = run_once(plan="tp", transport_override=None if one_dev else "rccl", emit=False)
-        barrier()
-        printed = threading.Lock()
 
-        def emit_and_leave(why):
-            if not printed.acquire(blocking=False):
-                return
-            if rank == 0:
-                out["library_choice"] = {"value": None, "skipped": why}
-                print(json.dumps(out), flush=True)
-            sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)                                   # (collectives of the abandoned run may never return: no orderly teardown)
+        def headline():
+            return run_once(plan="tp", transport_override=None if one_dev else "rccl", emit=False)
 
-        limit = float(os.environ.get("LMRS_BENCH_LIBRARY_CHOICE_TIMEOUT", "240"))
-        dog = threading.Timer(limit, emit_and_leave, args=(f"the library-choice run did not finish within {limit:.0f} s",))
-        dog.daemon = True; dog.start()
-        os.environ.pop("LMRS_SHARD_PLAN", None)            # (run_once(plan=...) set it for the headline run)
-        try:
-            lib_out = run_once(emit=False)
-            barrier()
-        except BaseException as e:                          # noqa: BLE001 - the headline line must get out whatever happened here
-            print(f"[rank {rank}] library-choice run failed: {type(e).__name__}: {e}", file=sys.stderr)
-            emit_and_leave(f"the library-choice run failed on a rank: {type(e).__name__}")
-            time.sleep(limit)                               # (another thread is printing: wait for its exit)
-        dog.cancel()
-        if printed.acquire(blocking=False) and rank == 0:
-            out["library_choice"] = {k: lib_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
-            out["library_choice"]["parallelism"] = lib_out["config"]["parallelism"]
-            out["library_choice"]["roofline"] = {k: lib_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}
-            print(json.dumps(out), flush=True)
+        def library_choice():
+            os.environ.pop("LMRS_SHARD_PLAN", None)        # (run_once(plan=...) set it for the headline run)
+            return run_once(emit=False)
+
+        out = headline_then_guarded(headline, library_choice, barrier, rank, float(os.environ.get("LMRS_BENCH_LIBRARY_CHOICE_TIMEOUT", "240")))
     if dist is not None:
         dist.destroy_process_group()
     return out

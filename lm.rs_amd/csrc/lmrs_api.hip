@@ -28,7 +28,6 @@
 #include <vector>
 
 #include "../../include/lmrs_hip.h"
-#include "lmrs_aql.h"
 #include "lmrs_format.h"
 #include "lmrs_kernels.h"
 
@@ -113,14 +112,7 @@ struct lmrs_ctx {
     int multi_k = 1; hipGraphExec_t g_multi[3] = {nullptr, nullptr, nullptr};
     // ---- final argmax folded into the classifier launch (ClsTail): packed partials
     bool cls_tail = false; unsigned long long* part_pk = nullptr; unsigned* cls_seq = nullptr;
-    // ---- the step as hand-written AQL packets on an HSA queue (lmrs_aql.h): one program per qa_mode, recorded on first use;
-    // lmrs_generate_greedy submits whole runs of steps through them (LMRS_AQL=0: hipGraph replays as before)
     int inj_fail_connect = 0, inj_stall_seg = -1; long long inj_stall_ticks = 0;      // lmrs_debug_inject
-    bool aql_on = false; int aql_fence = 1; AqlProgram* aql_prog[3] = {nullptr, nullptr, nullptr};
-    // three-part launch (launch_qkv_attn_wo, wave form only): per-layer granules of the quantised attention output
-    bool wo_merged = false; unsigned long long* qgran = nullptr;
-    // wo + w1/w3 as one launch (launch_wo_w13, round-4 prototype, LMRS_WO_W13=1): per-layer granules of the residual stream
-    bool wo13 = false; unsigned long long* xgran = nullptr;
 
     template <class T> T* alloc(size_t count) {
         size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
@@ -247,16 +239,6 @@ int enqueue_layer(lmrs_ctx* c, int l) {
         // 1 + 2 as ONE launch: the attention workgroups poll the granules the qkv workgroups write (launch_qkv_attn)
         g.gran = c->gran + (size_t)l * (c->att_dim + 2 * c->kv_dim); g.seq = c->seq;
         t.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-        if (c->qa_mode == 2 && c->wo_merged) {
-            // 1 + 2 + 3 as ONE launch (launch_qkv_attn_wo): the wo workgroups poll the attention output the head pairs publish quantised
-            GemvArgs w = g;
-            w.gran = nullptr; w.wq = L.wo; w.ws = L.so; w.n = c->att_dim; w.o = a.dim; w.xin = nullptr; w.rms_w = nullptr; w.out = c->x;
-            w.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-            const size_t qn = (size_t)c->att_dim / 4 + c->att_dim / 128;
-            HIP_OK(launch_qkv_attn_wo(g, PRO_RMS_QUANT, t, w, c->qgran + (size_t)l * qn, c->err, c->stream));
-            g.gran = nullptr; g.seq = nullptr;
-            goto after_wo;
-        }
         HIP_OK(launch_qkv_attn(g, pending ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, t, c->err, c->qa_max_T, c->qa_mode == 2, c->stream));
         g.gran = nullptr; g.seq = nullptr;
     } else {
@@ -268,17 +250,6 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     else HIP_OK(launch_attention(t, c->stream));
     }
     g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
-    if (c->wo13 && c->qa_mode && !c->att_split_chunks) {
-        // 3 + 4 as ONE launch (launch_wo_w13): the gate/up workgroups stream their weights under the wo rows and poll the new residual
-        GemvArgs w = g, h = g;
-        w.wq = L.wo; w.ws = L.so; w.n = c->att_dim; w.o = a.dim; w.xin = c->att_out; w.out = c->x;
-        w.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-        h.wq = L.w13; h.ws = L.s13; h.n = a.dim; h.o = 2 * a.hidden_dim; h.xin = nullptr; h.rms_w = L.rms_post_att; h.out = c->h;
-        h.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
-        set_launch_tag(3);
-        HIP_OK(launch_wo_w13(w, h, c->xgran + (size_t)l * a.dim, c->seq, c->err, c->stream));
-        goto after_w13;
-    }
     // 3. quantize | Wo | x += ...                                       (:550-576)
     g.wq = L.wo; g.ws = L.so; g.n = c->att_dim; g.o = a.dim; g.xin = c->att_out; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -286,7 +257,6 @@ int enqueue_layer(lmrs_ctx* c, int l) {
     HIP_OK(launch_gemv(g, PRO_QUANT, gemma ? EPI_STORE : EPI_RESID, c->stream));
     set_launch_tag(7);
     if (gemma && !c->gemma_fused) HIP_OK(launch_addnorm(c->x, c->tmp, L.rms_post_att, a.dim, a.rms_norm_eps, c->stream));   // :563-568
-after_wo:
     // 4. rmsnorm + quantize | W1,W3 interleaved | silu(g)*u             (:578-624)
     g.wq = L.w13; g.ws = L.s13; g.n = a.dim; g.o = 2 * a.hidden_dim; g.xin = c->x; g.rms_w = gemma ? L.rms_pre_ffn : L.rms_post_att; g.out = c->h;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -294,7 +264,6 @@ after_wo:
     set_launch_tag(3);
     HIP_OK(launch_gemv(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
     g.delta = nullptr; g.add_w = nullptr; g.xout = nullptr;
-after_w13:
     // 5. quantize | W2 | x += ...                                       (:630-654)
     g.wq = L.w2; g.ws = L.s2; g.n = a.hidden_dim; g.o = a.dim; g.xin = c->h; g.out = gemma ? c->tmp : c->x;
     g.dbg = c->dbg ? c->dbg + 8 * (c->dbg_node++) : nullptr;
@@ -603,28 +572,6 @@ int capture(lmrs_ctx* c, bool full, hipGraphExec_t* out, int n_steps = 1) {
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
     return 0;
-}
-
-// The launches of one decode step in form `mode` (qa_mode), recorded instead of enqueued and turned into AQL packets.  null: the
-// step cannot be expressed (a kernel the loader does not find, scratch memory): the context falls back to its graphs for good.
-AqlProgram* aql_step_program(lmrs_ctx* c, int mode) {
-    if (!c->aql_on) return nullptr;
-    if (c->aql_prog[mode]) return c->aql_prog[mode];
-    AqlRecorder rec;
-    const int keep = c->qa_mode;
-    aql_set_recorder(&rec);
-    c->qa_mode = mode; c->dbg_node = 0;
-    const int rc = enqueue_step(c);
-    c->qa_mode = keep;
-    aql_set_recorder(nullptr);
-    std::string why;
-    AqlProgram* p = rc ? nullptr : aql_program_create(c->device, rec, &why);
-    if (!p) {
-        c->aql_on = false;
-        if (getenv("LMRS_AQL_VERBOSE")) fprintf(stderr, "lmrs: AQL path off: %s\n", rc ? g_err.c_str() : why.c_str());
-        return nullptr;
-    }
-    return c->aql_prog[mode] = p;
 }
 
 // host->device copy of one tensor payload, optionally row-interleaved (dst row = 2*r + phase)
@@ -1067,38 +1014,8 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         if (c->qkv_att && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 1)) c->qa_wave_T = qkv_attn_wave_T((int)a.head_size);   // LMRS_QKV_ATT=1: workgroup form only
         if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = 0;                  // (its prefetch reads whole 64-row blocks of the caches)
     }
-    if (c->qkv_att && c->qa_wave_T > 0 && getenv("LMRS_WO_MERGED") && atoi(getenv("LMRS_WO_MERGED")) != 0) {
-        // ... and (LMRS_WO_MERGED=1, off by default) the wo GEMV in the same launch while the one-wave-per-head form lasts, when the shapes
-        // have a three-part class.  Measured in round 4 (bit-equal): 443 us per step against 426 for the separate wo launch - 433 with the
-        // wo workgroups' tile request delayed until the qkv rows' loads are through; the launch is as wide as its widest role (207 VGPRs:
-        // 512 of its 656 workgroups resident) and the polled hand-off costs what the boundary it replaces cost.
-        GemvArgs q{}; q.q4 = c->q4; q.n = a.dim; q.o = c->att_dim + 2 * c->kv_dim;
-        AttnArgs t{}; t.n_heads = a.n_heads; t.n_kv_heads = a.n_kv_heads; t.head_size = a.head_size; t.gemma = a.model_type == LMRS_GEMMA;
-        GemvArgs w{}; w.q4 = c->q4; w.n = c->att_dim; w.o = a.dim;
-        if (!c->gemma_fused && qkv_attn_wo_supported(q, PRO_RMS_QUANT, t, w)) {
-            c->qgran = c->alloc<unsigned long long>(nl * (att / 4 + att / 128));
-            if (!c->qgran) { fail("arena overflow"); return cleanup(); }
-            HCK(hipMemsetAsync(c->qgran, 0, nl * (att / 4 + att / 128) * 8, c->stream));
-            c->wo_merged = true;
-        }
-    }
-    if (c->qkv_att && !c->gemma_fused && !sharded && getenv("LMRS_WO_W13") && atoi(getenv("LMRS_WO_W13")) != 0) {
-        // (LMRS_WO_W13=1, off by default) wo and w1/w3 as one launch - the round-4 prototype of a persistent all-to-all edge, see launch_wo_w13
-        GemvArgs w{}; w.q4 = c->q4; w.n = c->att_dim; w.o = a.dim;
-        GemvArgs h{}; h.q4 = c->q4; h.n = a.dim; h.o = 2 * a.hidden_dim;
-        if (wo_w13_supported(w, h)) {
-            c->xgran = c->alloc<unsigned long long>(nl * dim);
-            if (!c->xgran) { fail("arena overflow"); return cleanup(); }
-            HCK(hipMemsetAsync(c->xgran, 0, nl * dim * 8, c->stream));
-            c->wo13 = true;
-        }
-    }
     if (!sharded) { const int k = getenv("LMRS_STEPS_PER_GRAPH") ? atoi(getenv("LMRS_STEPS_PER_GRAPH")) : 4; c->multi_k = k < 1 ? 1 : (k > 64 ? 64 : k); }   // (measured: 4 steps per launch +1.5 % on a 20-step run, no effect on long runs)
     c->cls_tail = !sharded && !f32w && V < (1u << 20) - 1 && !(getenv("LMRS_CLS_TAIL") && atoi(getenv("LMRS_CLS_TAIL")) == 0);
-    // hand-written AQL packets instead of graph replays for runs of decode steps (one GPU, quantised weights, the argmax folded in: every
-    // launch of such a step goes through the recordable launch macro)
-    c->aql_on = !sharded && !f32w && c->cls_tail && !getenv("LMRS_DEBUG_TIMELINE") && getenv("LMRS_AQL") && atoi(getenv("LMRS_AQL")) != 0;
-    c->aql_fence = getenv("LMRS_AQL_FENCE") ? atoi(getenv("LMRS_AQL_FENCE")) : 1;
     if (!sharded) {
         c->qa_mode = qa_mode_for(c, 0);
         CK(capture(c, true, &c->g_step));
@@ -1147,7 +1064,6 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->g_layers) (void)hipGraphExecDestroy(c->g_layers);
     for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : c->g_multi) if (g) (void)hipGraphExecDestroy(g);
-    for (auto& p : c->aql_prog) aql_program_destroy(p);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) (void)hipHostFree(c->h_logits);
@@ -1513,28 +1429,8 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     }
     if (set_state(c, start_pos + (uint32_t)done, start_pos + (uint32_t)n_prompt)) return -1;
     HIP_OK(launch_embed(embed_args(c), c->stream));
-    double aql_seconds = 0.0;
     for (size_t s = done; s < steps;) {
         const uint32_t p = start_pos + (uint32_t)s;
-        if (c->aql_on && !c->dbg) {
-            // every step up to the split-attention threshold as one submission of hand-written AQL packets (lmrs_aql.h)
-            std::vector<AqlProgram*> run;
-            for (size_t e = s; e < steps; ++e) {
-                const uint32_t pe = start_pos + (uint32_t)e;
-                if (c->att_split_pos > 0 && (int)pe >= c->att_split_pos) break;
-                AqlProgram* prog = aql_step_program(c, qa_mode_for(c, pe));
-                if (!prog) break;
-                run.push_back(prog);
-            }
-            if (!run.empty() && c->aql_on) {
-                HIP_OK(hipStreamSynchronize(c->stream));
-                std::string why; double sec = 0.0;
-                if (aql_run(c->device, run.data(), run.size(), c->aql_fence, &sec, &why)) return fail("AQL step: " + why);
-                aql_seconds += sec;
-                s += run.size();
-                continue;
-            }
-        }
         const int K = c->multi_k;
         const bool split_soon = c->att_split_pos > 0 && (int)(p + K - 1) >= c->att_split_pos;
         if (K > 1 && c->g_step && !c->dbg && s + K <= steps && !split_soon && qa_mode_for(c, p) == qa_mode_for(c, p + K - 1)) {
@@ -1558,7 +1454,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
     if (n_new) memcpy(out_tokens, c->h_tok, (size_t)n_new * 4);
-    if (seconds) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *seconds = ms * 1e-3 + aql_seconds; }
+    if (seconds) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, c->ev0, c->ev1)); *seconds = ms * 1e-3; }
     return 0;
 }
 
@@ -1673,7 +1569,7 @@ extern "C" int lmrs_bench_step(lmrs_ctx* c, uint32_t pos, int iters, double* us9
             const int kind = tags[i] >= 0 && tags[i] < 9 ? tags[i] : 7;
             us9[kind] += (double)ms * 1e3; count9[kind] += 1;
             const double att_bytes = 2.0 * kv * 4 * ((double)pos + it + 3);                       // attention: K and V rows up to this step's position (pos + 1 + it), read + the new row
-            bytes9[kind] += kind == 1 ? att_bytes : wbytes[kind] + (kind == 0 && merged ? att_bytes : 0.0) + (kind == 0 && qmode == 2 && c->wo_merged ? wbytes[2] : 0.0) + (kind == 3 && c->wo13 ? wbytes[2] : 0.0);   // merged launches: everything under the first kind
+            bytes9[kind] += kind == 1 ? att_bytes : wbytes[kind] + (kind == 0 && merged ? att_bytes : 0.0);   // merged launches: everything under the first kind
         }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -1741,7 +1637,7 @@ extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, 
     double b = L * ((dim * att + 2 * dim * kv + att * dim + 3 * dim * hid) * (bpe + 4.0 / 128.0) + n_norm * dim * 4) + V * dim * (bpe + 4.0 / 128.0) +
                dim * 4 + L * 2 * kv * 4 * ((double)pos + 2);
     if (algo_bytes) *algo_bytes = b;
-    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (qa_mode_for(c, pos) && !(c->att_split_pos > 0 && (int)pos >= c->att_split_pos) ? ((qa_mode_for(c, pos) == 2 && c->wo_merged) || c->wo13 ? 3 : 4) : 5)) * (int)a.n_layers + (c->cls_tail ? 1 : 2);
+    if (n_launches) *n_launches = (a.model_type == LMRS_GEMMA && !c->gemma_fused ? 7 : (qa_mode_for(c, pos) && !(c->att_split_pos > 0 && (int)pos >= c->att_split_pos) ? 4 : 5)) * (int)a.n_layers + (c->cls_tail ? 1 : 2);
     return 0;
 }
 

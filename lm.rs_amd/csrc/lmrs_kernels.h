@@ -14,20 +14,14 @@ struct DevState {
     int win_base;     // >= 0: first position of a batched forward_layer call (Gemma window quirk, see attention_body); < 0: decode
 };
 
-enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3,   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
-                // merged qkv + attention + wo launch: the quantised attention output arrives as {4 x int8, tag} / {scale, tag} granules written inside the same launch
-                PRO_PREQ_TAG = 4,
-                // wo + w1/w3 as one launch (round-4 prototype): the residual stream arrives as {f32, tag} granules the wo workgroups of the SAME launch write
-                PRO_RMS_QUANT_TAG = 5 };
+enum Prologue { PRO_PREQ = 0, PRO_QUANT = 1, PRO_RMS_QUANT = 2, PRO_ADD_RMS_QUANT = 3 };   // 3: x + rmsnorm(delta), then rmsnorm, quantise (static kernels only)
 enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_CLS = 4, EPI_GELU = 5,
                 // CLIP tower (batched GEMM only): + bias with q / sqrt(head) | + bias + residual | + bias, QuickGELU
                 EPI_VQKV = 6, EPI_BIAS_RESID = 7, EPI_BIAS_QGELU = 8,
                 // image projector (processor.rs:234-342): + bias, tanh-GELU | + bias
                 EPI_BIAS_GELU = 9, EPI_BIAS = 10,
                 // merged qkv + attention launch: q / raw k / v leave as 8-byte {value, tag} granules (write-through), v also to its cache row
-                EPI_QKV_TAG = 11,
-                // wo + w1/w3 as one launch: x += ..., and every new x value also leaves as a {value, tag} granule
-                EPI_RESID_TAG = 12 };
+                EPI_QKV_TAG = 11 };
 
 struct EmbedArgs {
     const void* emb_q; const float* emb_s; int q4;
@@ -80,9 +74,6 @@ struct GemvArgs {
     const DevState* st;
     // EPI_QKV_TAG: gran[row] = {value, tag = *seq + 1}; seq = steps finished so far on this context (never reset)
     unsigned long long* gran; const unsigned* seq;
-    // PRO_PREQ_TAG: n/4 granules {4 x int8, tag} then n/128 granules {scale, tag}; err: set when a bounded poll gives up
-    const unsigned long long* gran_in; int* err;
-    int tag_sleep0, tag_sleep1;   // PRO_PREQ_TAG: s_sleep(16) rounds (~0.43 us each) before the weight tile is requested / before the first poll
     // EPI_CLS
     float* part_val; int* part_idx; int softcap_rows;   // Gemma: tanh soft-cap on (global) rows < softcap_rows
     const unsigned* part_par; int part_par_floats;      // the partials go to the half the NEXT exchange of their slot will push: ((*part_par + 1) & 1) * part_par_floats (see ArgmaxArgs)
@@ -123,24 +114,10 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 // rows of the earlier positions and poll the {value, tag} granules the GEMV workgroups of the same launch write (g.gran, g.seq).
 // max_T: longest context (pos + 1) the launch will ever see (sizes the LDS score vector).  hipErrorNotSupported: no merged class
 // for this shape - the caller launches the two kernels separately.
-struct QkvAttnArgs { GemvArgs g; AttnArgs t; int* err; GemvArgs w; unsigned long long* qgran; };   // w / qgran: the wo GEMV of the three-part form (launch_qkv_attn_wo)
+struct QkvAttnArgs { GemvArgs g; AttnArgs t; int* err; };
 bool qkv_attn_supported(const GemvArgs& g, int pro, const AttnArgs& t);
 int qkv_attn_wave_T(int head_size);       // longest context (pos + 1) of the one-wave-per-head form; 0: none for this head size
 hipError_t launch_qkv_attn(const GemvArgs& g, int pro, const AttnArgs& t, int* err, int max_T, bool wave, hipStream_t s);
-// ... and the wo GEMV as well (one-wave-per-head form only, head size 64, Q8_0): two heads - one 128-value quantisation group - share a
-// workgroup, quantise their outputs together (quantization.rs:44-67, the device functions of the PRO_QUANT prologue) and publish
-// them as {4 x int8, tag} / {scale, tag} granules (qgran: att_dim/4 + att_dim/128); the wo workgroups of the same launch, their weight
-// tile already in registers, poll the 4 KB quantised vector straight into LDS and run their rows.  w: the arguments of the separate
-// wo launch (w.xin unused).  hipErrorNotSupported: no class for this shape.
-bool qkv_attn_wo_supported(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w);
-hipError_t launch_qkv_attn_wo(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w, unsigned long long* qgran, int* err, hipStream_t s);
-// wo + w1/w3 as ONE launch (round-4 prototype of a persistent edge, Llama-3.2-1B Q8_0 shapes): the wo workgroups come first in the grid
-// and publish every new residual value as a granule as well; the gate/up workgroups request their whole weight share (both passes) at
-// kernel start, poll the 2048 granules straight into the registers the norm prologue works on, and run as usual.  w / g: the
-// arguments of the two separate launches (g.xin unused); xgran: dim granules; tiles: 1 = only the first pass's tile before the poll.
-struct WoW13Args { GemvArgs w, g; int n_wo; };
-bool wo_w13_supported(const GemvArgs& w, const GemvArgs& g);
-hipError_t launch_wo_w13(const GemvArgs& w, const GemvArgs& g, unsigned long long* xgran, const unsigned* seq, int* err, hipStream_t s);
 // long contexts: scores by (head, 256-key chunk), softmax + V by (head, quarter of the dims); S: attention_split_scratch_floats(..)
 size_t attention_split_scratch_floats(int n_heads, int seq_len);
 hipError_t launch_attention_split(const AttnArgs& a, float* S, int n_key_chunks, hipStream_t s);

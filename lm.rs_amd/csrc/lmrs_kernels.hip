@@ -32,7 +32,6 @@
 #include <set>
 #include <utility>
 
-#include "lmrs_aql.h"
 #include "lmrs_device_math.h"
 #include "lmrs_kernels.h"
 #include "lmrs_stage.h"
@@ -624,46 +623,7 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// In-launch hand-off of a QUANTISED activation (merged qkv + attention + wo launch): the producers publish 128-value groups as 32
-// granules {4 x int8, tag} + one {scale, tag} (write-through stores: the data is the flag, as in the merged qkv + attention launch);
-// preq_poll brings the whole vector straight into the LDS image the GEMV rows read.  Every poll is bounded (err).
-// ------------------------------------------------------------------------------------------------
-constexpr unsigned kTagSpinMax = 1u << 20;
-// the whole workgroup: quantised activation of N elements, granules -> xq[N] int8, xs[N/128] f32 in LDS (the caller's lds_barrier()
-// publishes it to the workgroup).  The producers are seconds of arithmetic away when the workgroup arrives: one long sleep first, then
-// a sweep every ~0.4 us.
-template <int N, int NTH>
-__device__ __forceinline__ void preq_poll(const GemvArgs& a, int8_t* xq, float* xs, unsigned tag, unsigned long long* dbg) {
-    constexpr int NI = N / 4, G = N / 128, SL = (NI + G + NTH - 1) / NTH;
-    const int t = threadIdx.x;
-    const unsigned long long* gi = a.gran_in;
-    for (int i = 0; i < a.tag_sleep1; ++i) __builtin_amdgcn_s_sleep(16);           // nothing can be there earlier
-    unsigned long long x[SL];
-    for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < SL; ++i) { const int k = t + i * NTH; x[i] = __hip_atomic_load(gi + (k < NI + G ? k : NI + G - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#pragma unroll
-        for (int i = 0; i < SL; ++i) ok = ok && (unsigned)(x[i] >> 32) == tag;
-        if (__syncthreads_and(ok)) break;                                          // (workgroup-uniform exit: every lane leaves with fresh values)
-        if (spins > kTagSpinMax || (spins & 1023) == 1023) {                       // bounded: report and finish with garbage instead of hanging (uniform decision)
-            const int e = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__syncthreads_or(e != 0 || spins > kTagSpinMax)) {
-                if (t == 0 && e == 0) __hip_atomic_store(a.err, 3000 + a.layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        __builtin_amdgcn_s_sleep(16);
-    }
-    if (dbg && t == 0) dbg[4] = wall_clock64();
-#pragma unroll
-    for (int i = 0; i < SL; ++i) {
-        const int k = t + i * NTH;
-        if (k < NI) reinterpret_cast<unsigned*>(xq)[k] = (unsigned)x[i];
-        else if (k < NI + G) xs[k - NI] = __uint_as_float((unsigned)x[i]);
-    }
-}
+constexpr unsigned kTagSpinMax = 1u << 20;           // bound of every in-launch poll (err is set, the launch finishes with garbage instead of hanging)
 
 // The value of lane i + D (D = 8 / 16: the up row of a gate row of L = D lanes) without the LDS crossbar round trip of __shfl_down:
 // row_shl:8 inside a 16-lane row; across rows gfx950's v_permlane16_swap (with both operands = v its second result is [r1 r1 r3 r3]).
@@ -702,9 +662,8 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane % L;
     const int o = a.o, n_pass = (o + R::RB - 1) / R::RB;
     const int8_t* wq = reinterpret_cast<const int8_t*>(a.wq);
-    constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT || PRO == PRO_RMS_QUANT_TAG;
-    constexpr bool XTAG = PRO == PRO_RMS_QUANT_TAG;                                    // x arrives as granules written inside this launch
-    constexpr bool PREQ = PRO == PRO_PREQ || PRO == PRO_PREQ_TAG;                      // the activation arrives quantised
+    constexpr bool HAS_RMS = PRO == PRO_RMS_QUANT || PRO == PRO_ADD_RMS_QUANT;
+    constexpr bool PREQ = PRO == PRO_PREQ;                                             // the activation arrives quantised
 
     unsigned ctag = 0; TailPre tpre{}; int pofs = 0;
     if constexpr (EPI == EPI_CLS) {
@@ -713,11 +672,11 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     }
     int pos_pre = 0; unsigned tag_pre = 0;
     if constexpr (EPI == EPI_QKV || EPI == EPI_QKV_TAG) pos_pre = a.st->pos;      // the kernel's first load: nothing it has to wait behind
-    if constexpr (EPI == EPI_QKV_TAG || PRO == PRO_PREQ_TAG || EPI == EPI_RESID_TAG || XTAG) tag_pre = *a.seq + 1u;
+    if constexpr (EPI == EPI_QKV_TAG) tag_pre = *a.seq + 1u;
     float4 v[V::NP], nw[V::NP], dl[V::NP], aw[V::NP];
     if constexpr (!PREQ) {
         if constexpr (PRO == PRO_ADD_RMS_QUANT) { vec_load<N, false, NTH>(dl, a.delta); vec_load<N, false, NTH>(aw, a.add_w); }
-        if constexpr (!XTAG) vec_load<N, false, NTH>(v, a.xin);
+        vec_load<N, false, NTH>(v, a.xin);
         if constexpr (HAS_RMS) vec_load<N, false, NTH>(nw, a.rms_w);
     }
     auto row_of = [&](int pass) __attribute__((always_inline)) { const int rw = pass * R::RB + wave * R::RW + lane / L; return rw < o ? rw : o - 1; };
@@ -726,19 +685,10 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     asm volatile("" ::: "memory");               // keep the activation loads ahead of the weight tile in issue order
     // A CU returns vector-memory data in request order across its waves: without this barrier the activation loads of
     // the workgroup's later waves (L2 hits) queue behind the earlier waves' weight tiles (HBM misses).
-    if (!PREQ && !XTAG && a.order_barrier) __builtin_amdgcn_s_barrier();
+    if (!PREQ && a.order_barrier) __builtin_amdgcn_s_barrier();
     // (waiting for the activation before issuing the tile, or issuing only part of it first, was measured: no gain)
     WTile<R::U> ta, tb;
     int pass = bid;                      // grid <= n_pass
-    if constexpr (PRO == PRO_PREQ_TAG) {
-        // the workgroups ahead in the grid (the qkv rows) are on the launch's critical path: this tile must not queue in front of theirs
-        for (int i = 0; i < a.tag_sleep0; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-    if constexpr (XTAG) {
-        // (same for the wo rows ahead of the gate/up workgroups: requested at once, 33 MB of gate/up tiles put the wo rows' 4 MB at the
-        // back of every memory queue - wo finished at 5.1 us instead of 1.4)
-        for (int i = 0; i < a.tag_sleep1; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     tile_issue<N, L, Q4>(ta, wq, a.ws, row_of(pass));
     // (requesting the second pass's tile here as well - it would stream under the prologue - was measured slower on every model, Gemma's
     // 5 us folded prologue included: the more bytes are queued ahead of a workgroup's activation loads, the later they land)
@@ -747,53 +697,18 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
     // touches it during the launch) and the position the QKV epilogue stores the V row at.
     // (unconditional, every lane of the row: a load under a lane predicate would cost the kernel its counted vmcnt waits)
     float resid0 = 0.0f;
-    if constexpr (EPI == EPI_RESID || EPI == EPI_RESID_TAG) resid0 = a.out[row_of(pass)];
-    if constexpr (XTAG) {
-        // the whole weight share before the poll: the second pass's tile too (nothing latency-critical of this workgroup is queued behind it)
-        if (a.tag_sleep0 >= 2) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(bid + nblk));
-    }
+    if constexpr (EPI == EPI_RESID) resid0 = a.out[row_of(pass)];
     // (two-pass launches: issuing the second tile here as well was measured - slower on every model: the more bytes the
     // chip has in flight, the later every workgroup's activation lands)
     __builtin_amdgcn_sched_barrier(0);           // the prologue's first wait must not be scheduled above the tile's loads
 
-    if constexpr (PRO == PRO_PREQ_TAG) {
-        static_assert(PRO != PRO_PREQ_TAG || !Q4, "granule hand-off: Q8_0 activations");
-        preq_poll<N, NTH>(a, xq, xs, tag_pre, bid == 0 ? a.dbg : nullptr);         // (the weight tile requested above has landed long before)
-    } else if constexpr (PRO == PRO_PREQ) {
+    if constexpr (PRO == PRO_PREQ) {
         constexpr int XB = Q4 ? N / 2 : N;
         for (int e = threadIdx.x * 16; e < XB; e += NTH * 16)
             *reinterpret_cast<int4*>(xq + e) = *reinterpret_cast<const int4*>(preq_bytes(a, e));
         for (int g = threadIdx.x; g < V::G; g += NTH) xs[g] = preq_scale(a, g);
     } else {
         unsigned long long* dbg = bid == 0 ? a.dbg : nullptr;
-        if constexpr (XTAG) {
-            // every lane polls the granules of the 4 x NP values it owns (the whole workgroup: all N); a wave leaves when its own are this
-            // step's - the norm's first barrier then joins the waves.  Bounded (err).
-            static_assert(V::FULL, "granule hand-off: whole passes");
-            const unsigned long long* gp = a.gran_in;
-            unsigned long long x[V::NP][4];
-            for (unsigned spins = 0;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < V::NP; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) x[i][k] = __hip_atomic_load(gp + V::elem(i, (int)threadIdx.x) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int i = 0; i < V::NP; ++i)
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) ok = ok && (unsigned)(x[i][k] >> 32) == tag_pre;
-                if (__all(ok)) break;
-                if (spins > kTagSpinMax || (spins & 1023) == 1023) {
-                    const int e = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (e != 0 || spins > kTagSpinMax) { if (e == 0) __hip_atomic_store(a.err, 4000 + a.layer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-#pragma unroll
-            for (int i = 0; i < V::NP; ++i)
-                v[i] = make_float4(__uint_as_float((unsigned)x[i][0]), __uint_as_float((unsigned)x[i][1]), __uint_as_float((unsigned)x[i][2]), __uint_as_float((unsigned)x[i][3]));
-            if (dbg && threadIdx.x == 0) dbg[6] = wall_clock64();
-        }
         if constexpr (PRO == PRO_ADD_RMS_QUANT) {
             // (Round 4, measured and removed: requesting the second pass's tile from inside this ~5 us prologue, once the branch output has
             // landed.  Gemma-2-2B Q4_0: 889 -> 894 us per step with three passes per workgroup, 898 -> 952 with two - the tiles of 288
@@ -824,12 +739,6 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
             if (valid && writer) a.out[row] = acc;
         } else if constexpr (EPI == EPI_RESID) {
             if (valid && writer) a.out[row] = (ps == bid ? resid0 : a.out[row]) + acc;
-        } else if constexpr (EPI == EPI_RESID_TAG) {
-            if (valid && writer) {
-                const float xn = (ps == bid ? resid0 : a.out[row]) + acc;
-                a.out[row] = xn;                                                     // for the launches that follow
-                __hip_atomic_store(a.gran + row, ((unsigned long long)tag_pre << 32) | __float_as_uint(xn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the gate/up workgroups of THIS launch
-            }
         } else if constexpr (EPI == EPI_QKV) {
             if (valid && writer) {
                 if (row < a.att_dim) a.out[row] = acc;
@@ -872,7 +781,7 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
         for (;;) {
             const int p1 = pass + nblk;
             const bool have1 = p1 < n_pass;
-            if (have1 && !(XTAG && a.tag_sleep0 >= 2 && pass == bid)) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));     // (XTAG: on its way since kernel start)
+            if (have1) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p1));
             const float acc_a = tile_consume<N, L, Q4>(ta, xq, xs);
             if (pass == bid) LMRS_STAMP0(2);
             const int p2 = p1 + nblk;
@@ -885,15 +794,11 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
             const int p3 = p2 + nblk;
             const bool have3 = have2 && p3 < n_pass;
             float acc_c = 0.0f;
-#ifndef LMRS_GLU_PAIRS
             if (have2) {                                                   // wave-uniform
                 if (have3) tile_issue<N, L, Q4>(tb, wq, a.ws, row_of(p3));
                 acc_c = tile_consume<N, L, Q4>(ta, xq, xs);
             }
             const bool third = have2;
-#else
-            const bool third = false;
-#endif
             const float up_a = lane_plus<L>(acc_a), up_b = lane_plus<L>(acc_b), up_c = lane_plus<L>(acc_c);         // rows interleaved: 2i gate, 2i+1 up
             const float gate_b1 = dpp_f<0x111>(acc_b), up_b1 = dpp_f<0x111>(up_b);           // pass B's pair, one lane up
             const float gate_c2 = dpp_f<0x112>(acc_c), up_c2 = dpp_f<0x112>(up_c);           // pass C's pair, two lanes up
@@ -908,13 +813,9 @@ __device__ __forceinline__ void gemv_static_body(const GemvArgs& a, char* smem, 
             if (lane_a && row_a < o) a.out[row_a >> 1] = hval;
             if (lane_b && row_b < o) a.out[row_b >> 1] = hval;
             if (lane_c && row_c < o) a.out[row_c >> 1] = hval;
-#ifndef LMRS_GLU_PAIRS
-            if (!have3) break;
-            pass = p3;
-#else
-            if (!have2) break;
-            pass = p2;
-#endif
+            // (a fourth pass would find its tile in `tb` while the next round consumes `ta` first: gemv_grid / launch_gemv never give a gate/up
+            // workgroup more than three passes, and the loop ends here)
+            break;
         }
     } else
     // double-buffered passes
@@ -968,8 +869,14 @@ __device__ __forceinline__ GemvArgs with_hot(const GemvArgs& a0, const float* xi
 #define LMRS_HOT_PARAMS const float* h_xin, const void* h_wq, const float* h_ws, const float* h_rms_w, const DevState* h_st, const unsigned* h_seq, float* h_out
 #define LMRS_HOT_OF(g) (g).xin, (g).wq, (g).ws, (g).rms_w, (g).st, (g).seq, (g).out
 
+// (A/B: -DLMRS_W2_MIN_WAVES=4 asks for two 512-thread workgroups per CU - at most 128 VGPRs - for the w2 classes)
+#ifdef LMRS_W2_MIN_WAVES
+#define LMRS_STATIC_BOUNDS(NTH_) __launch_bounds__(NTH_, (NTH_) == 512 ? LMRS_W2_MIN_WAVES : 1)
+#else
+#define LMRS_STATIC_BOUNDS(NTH_) __launch_bounds__(NTH_)
+#endif
 template <int N, int L, int PRO, int EPI, int NTH, bool Q4 = false>
-__global__ __launch_bounds__(NTH) void gemv_static_kernel(LMRS_HOT_PARAMS, const GemvArgs a0) {
+__global__ LMRS_STATIC_BOUNDS(NTH) void gemv_static_kernel(LMRS_HOT_PARAMS, const GemvArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemvArgs a = with_hot(a0, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out);
     gemv_static_body<N, L, PRO, EPI, NTH, Q4>(a, smem, (int)blockIdx.x, (int)gridDim.x);
@@ -1052,8 +959,7 @@ bool next_launch_events(hipEvent_t* a, hipEvent_t* b) {
 #define LMRS_LAUNCH_GRID(kern, grid3, nt, smem, s, ...)                                                     \
     do {                                                                                                    \
         hipEvent_t ea_, eb_;                                                                                \
-        if (aql_recorder()) aql_record(reinterpret_cast<const void*>(kern), grid3, (unsigned)(nt), smem, __VA_ARGS__);   /* the step is being recorded as AQL packets (lmrs_aql.h) */ \
-        else if (next_launch_events(&ea_, &eb_)) hipExtLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, ea_, eb_, 0, __VA_ARGS__); \
+        if (next_launch_events(&ea_, &eb_)) hipExtLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, ea_, eb_, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid3, dim3(nt), smem, s, __VA_ARGS__);                               \
     } while (0)
 #define LMRS_LAUNCH_NT(kern, grid, nt, smem, s, a) LMRS_LAUNCH_GRID(kern, dim3(grid), nt, smem, s, a)
@@ -1160,15 +1066,15 @@ int gemv_grid(const GemvArgs& a, int pro, int epi) {
     const int RB = (64 / sh.L) * ((sc.L ? sc.nt : kBlock) / 64);
     const int n_pass = (a.o + RB - 1) / RB;
     int cap = 4096;
+    static const int w2_cap = env_flag("LMRS_W2_GRID_CAP", 0);     // (A/B, round 5)
+    if (sc.L && sc.nt == 512 && w2_cap > 0) cap = w2_cap;
     if (epi == EPI_CLS) cap = 512;                         // classifier: persistent-style grid, prologue paid once per workgroup
     else if (sc.L && (epi == EPI_SWIGLU || epi == EPI_GELU)) {                             // w1w3: two passes per workgroup ...
-        static const int forced = env_flag("LMRS_GLU_PASSES", 0);
         int k = 2;
         // ... unless that leaves a grid between one and two workgroups per CU (Gemma-2-2B: 288 on 256 CUs - 32 CUs then carry twice the
         // stream and two prologues, and the launch ends with them): three passes per workgroup when that fits one per CU
         if (n_pass / 2 > 256 && n_pass / 2 < 448 && (n_pass + 2) / 3 <= 256) k = 3;
-        if (forced > 0) k = forced;
-        cap = (n_pass + k - 1) / k;
+        cap = (n_pass + k - 1) / k;                        // (never more than three: the gate/up loop of gemv_static_body takes up to three passes)
     }
     return n_pass < cap ? n_pass : cap;
 }
@@ -1179,7 +1085,11 @@ hipError_t launch_gemv(const GemvArgs& a0, int pro, int epi, hipStream_t s, int 
     GemvArgs a = a0;
     a.order_barrier = order_barrier; a.chain_spread = chain_spread;
     if (a.n % kGS != 0 || a.n > kMaxP * 1024 || a.o <= 0) return hipErrorInvalidValue;
-    const int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
+    int grid = grid_hint > 0 ? grid_hint : gemv_grid(a, pro, epi);
+    if (grid_hint > 0 && (epi == EPI_SWIGLU || epi == EPI_GELU)) {      // a caller's grid must not give a gate/up workgroup more than the three passes its loop takes
+        const int least = gemv_grid(a, pro, epi);
+        if (grid < least) grid = least;
+    }
     if (epi == EPI_CLS && a.has_tail && (!a.tail.cls_seq || !a.tail.err || !a.tail.part_pk || a.o + a.row_offset >= (1 << 20) - 1)) return hipErrorInvalidValue;
     const size_t smem = gemv_smem(a, pro);
     const StaticClass sc = static_class(a, pro, epi);
@@ -1638,10 +1548,8 @@ template <int HS> struct WaveGeom {
 };
 constexpr int qa_wave_T(int hs) { return hs == 64 ? 128 : ((hs == 96 || hs == 128) ? 64 : 0); }   // 0: no wave class (Gemma's 256-wide heads)
 
-// (three-part launch: wo.qg != null - the head's outputs also leave quantised, see WoTag)
-struct WoTag { unsigned long long* qg; float* pair; int n_int; };    // qgran, the two waves' LDS exchange slot (2 floats), att_dim / 4
 template <int HS, bool GEMMA>
-__device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg, const WoTag& wo = WoTag()) {
+__device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
     using W = WaveGeom<HS>;
     constexpr int HS4 = W::HS4, ND = W::ND, NH2 = W::NH2, TW = W::TW, NPASS = W::NPASS, half = HS / 2;
     const int lane = threadIdx.x & 63;                              // one wave per head (the caller retired the workgroup's other waves)
@@ -1896,28 +1804,6 @@ __device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int 
         o[i] = o[i] + pr;
         if (d < HS) a.out[h * HS + d] = o[i];
     }
-    if constexpr (HS == 64) {
-        if (wo.qg) {
-            // heads 2g and 2g+1 are the two waves of this workgroup and together one 128-value quantisation group of the wo input:
-            // quantize (quantization.rs:44-67) with vec_quantize_q8's arithmetic - group maximum (order-free), scale = max / 127 by IEEE
-            // division, candidates by reciprocal with the exact redo - and publish it for the wo workgroups of this launch
-            const float x = o[0];
-            float m = wave64_max(fabsf(x));
-            if (lane == 0) wo.pair[h & 1] = m;
-            lds_barrier();                                               // the workgroup's two live waves
-            m = fmaxf(wo.pair[0], wo.pair[1]);
-            const float sc = m / 127.0f, inv = __builtin_amdgcn_rcpf(sc);
-            float dev = 0.0f;
-            int q = quant_q8_try(x, inv, dev);
-            if (quant_slow(m, dev)) q = quant_q8(x, sc);
-            const unsigned b = (unsigned)q & 0xffu;
-            unsigned w = b;
-            w |= (unsigned)__shfl_down((int)b, 1) << 8; w |= (unsigned)__shfl_down((int)b, 2) << 16; w |= (unsigned)__shfl_down((int)b, 3) << 24;
-            const unsigned long long tg64 = (unsigned long long)tg.tag << 32;
-            if ((lane & 3) == 0) __hip_atomic_store(wo.qg + (h * HS + lane) / 4, tg64 | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0 && (h & 1) == 0) __hip_atomic_store(wo.qg + wo.n_int + h / 2, tg64 | __float_as_uint(sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
 }
 
@@ -1994,105 +1880,6 @@ hipError_t launch_qkv_attn(const GemvArgs& g0, int pro, const AttnArgs& t0, int*
     LMRS_QA_TABLE(X)
 #undef X
     return hipErrorNotSupported;
-}
-
-// ------------------------------------------------------------------------------------------------
-// qkv + attention + wo as ONE launch (one-wave-per-head form, head size 64, Q8_0).  Workgroups [0, n_heads/2): two attention waves,
-// heads 2b and 2b+1 (the other waves retire); then the qkv GEMV workgroups (EPI_QKV_TAG); then the wo GEMV workgroups, which request
-// their weight tile, sleep through the qkv and attention phases, poll the quantised attention output (preq_poll) and run their rows
-// with the residual epilogue.  Nobody waits for a workgroup behind it in the grid and every workgroup is resident at once; all polls
-// are bounded.  Arithmetic: attention_wave_tag, vec_quantize_q8's, the static GEMV body - bit-identical to the separate launches.
-// ------------------------------------------------------------------------------------------------
-template <int N, int L, int PRO, int HS, int NW_, int LW>
-__global__ __launch_bounds__(kBlock) void qkv_attn_wo_kernel(LMRS_HOT_PARAMS, const QkvAttnArgs a0, const int n_qkv) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    QkvAttnArgs a = a0;                                              // (kernel-argument preload: see gemv_static_kernel)
-    a.g = with_hot(a0.g, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out); a.t.st = h_st; a.w.seq = h_seq;
-    const int npair = a.t.n_heads / 2, b = (int)blockIdx.x;
-    if (b < npair) {
-        if (threadIdx.x >= 128) return;                            // two waves: no workgroup barrier below except the pair's own
-        const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const uint64_t etab = exp2f_tab_lane();
-        const int pos = a.t.st->pos;
-        const AttTag tg{a.g.gran, *a.g.seq + 1u, a.g.att_dim, a.g.kv_dim, a.err};
-        constexpr size_t WS = (WaveGeom<HS>::SMEM + 15) & ~(size_t)15;
-        const WoTag wo{a.qgran, reinterpret_cast<float*>(smem + 2 * WS), a.g.att_dim / 4};
-        attention_wave_tag<HS, false>(a.t, 2 * b + wv, pos, smem + wv * WS, etab, tg, wo);
-    } else if (b < npair + n_qkv) {
-        gemv_static_body<N, L, PRO, EPI_QKV_TAG, kBlock, false>(a.g, smem, b - npair, n_qkv);
-    } else {
-        gemv_static_body<NW_, LW, PRO_PREQ_TAG, EPI_RESID, kBlock, false>(a.w, smem, b - npair - n_qkv, (int)gridDim.x - npair - n_qkv);
-    }
-}
-
-// the three-part classes: (dim, lanes per qkv row, qkv prologue, head size, att_dim, lanes per wo row)
-#define LMRS_QAW_TABLE(X) X(2048, 32, PRO_RMS_QUANT, 64, 2048, 32)      /* Llama-3.2-1B Q8_0 */
-
-bool qkv_attn_wo_supported(const GemvArgs& g, int pro, const AttnArgs& t, const GemvArgs& w) {
-    if (!qkv_attn_supported(g, pro, t) || g.q4 || w.q4 || t.gemma || (t.n_heads & 1) || qa_wave_T(t.head_size) <= 0 || w.n != t.n_heads * t.head_size) return false;
-    const StaticClass sc = static_class(g, pro, EPI_QKV), sw = static_class(w, PRO_PREQ, EPI_RESID);
-#define X(n_, l_, p_, hs_, nw_, lw_) if (g.n == n_ && sc.L == l_ && pro == p_ && t.head_size == hs_ && w.n == nw_ && sw.L == lw_ && sw.nt == kBlock && w.o == n_) return true;
-    LMRS_QAW_TABLE(X)
-#undef X
-    return false;
-}
-
-hipError_t launch_qkv_attn_wo(const GemvArgs& g0, int pro, const AttnArgs& t0, const GemvArgs& w0, unsigned long long* qgran, int* err, hipStream_t s) {
-    static const int order_barrier = env_flag("LMRS_ORDER_BARRIER", 1);
-    if (!qkv_attn_wo_supported(g0, pro, t0, w0) || !g0.gran || !g0.seq || !err || !qgran) return hipErrorNotSupported;
-    QkvAttnArgs a{g0, t0, err, w0, qgran};
-    a.g.order_barrier = order_barrier; a.g.chain_spread = env_flag("LMRS_CHAIN_SPREAD", 1);
-    a.w.order_barrier = order_barrier; a.w.gran_in = qgran; a.w.err = err; a.w.seq = g0.seq;
-    a.w.tag_sleep0 = env_flag("LMRS_WO_SLEEP0", 0); a.w.tag_sleep1 = env_flag("LMRS_WO_SLEEP1", 6);
-    a.t.chunk = qa_chunk(t0.head_size);
-    const int n_qkv = gemv_grid(a.g, pro, EPI_QKV), n_wo = gemv_grid(a.w, PRO_PREQ, EPI_RESID);
-    const int grid = t0.n_heads / 2 + n_qkv + n_wo;
-#define X(n_, l_, p_, hs_, nw_, lw_)                                                                                     \
-    if (a.g.n == n_ && pro == p_ && t0.head_size == hs_ && a.w.n == nw_) {                                               \
-        size_t smem = 2 * ((WaveGeom<hs_>::SMEM + 15) & ~(size_t)15) + 16;                                              \
-        const size_t gs = gemv_smem(a.g, pro), ws = gemv_smem(a.w, PRO_PREQ);                                           \
-        if (gs > smem) smem = gs;                                                                                        \
-        if (ws > smem) smem = ws;                                                                                        \
-        if (smem > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(qkv_attn_wo_kernel<n_, l_, p_, hs_, nw_, lw_>)); \
-        LMRS_LAUNCH_GRID((qkv_attn_wo_kernel<n_, l_, p_, hs_, nw_, lw_>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a, n_qkv);        \
-        return hipGetLastError();                                                                                        \
-    }
-    LMRS_QAW_TABLE(X)
-#undef X
-    return hipErrorNotSupported;
-}
-
-// ------------------------------------------------------------------------------------------------
-// wo + w1/w3 as ONE launch (round-4 prototype of a persistent all-to-all edge; LMRS_WO_W13=1).  Workgroups [0, n_wo): the wo GEMV,
-// unchanged but for its epilogue (EPI_RESID_TAG: x also leaves as granules).  The gate/up workgroups behind them request their weight
-// tiles at kernel start - the stream that otherwise begins one boundary + one ramp after wo's last store runs under wo - then poll the
-// 2048 granules into the registers of the norm prologue (PRO_RMS_QUANT_TAG).  All workgroups are resident at once (3 per CU at 168
-// VGPRs); nobody waits for a workgroup behind it; polls are bounded.  Arithmetic: the two static bodies - bit-identical.
-// ------------------------------------------------------------------------------------------------
-template <int NW_, int LW, int N, int L>
-__global__ __launch_bounds__(kBlock) void wo_w13_kernel(const WoW13Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = (int)blockIdx.x;
-    if (b < a.n_wo) gemv_static_body<NW_, LW, PRO_QUANT, EPI_RESID_TAG, kBlock, false>(a.w, smem, b, a.n_wo);
-    else gemv_static_body<N, L, PRO_RMS_QUANT_TAG, EPI_SWIGLU, kBlock, false>(a.g, smem, b - a.n_wo, (int)gridDim.x - a.n_wo);
-}
-bool wo_w13_supported(const GemvArgs& w, const GemvArgs& g) {
-    if (w.q4 || g.q4 || w.n != 2048 || w.o != 2048 || g.n != 2048 || g.o != 16384) return false;
-    const StaticClass sw = static_class(w, PRO_QUANT, EPI_RESID), sg = static_class(g, PRO_RMS_QUANT, EPI_SWIGLU);
-    return sw.L == 32 && sw.nt == kBlock && sg.L == 16 && sg.nt == kBlock;
-}
-hipError_t launch_wo_w13(const GemvArgs& w0, const GemvArgs& g0, unsigned long long* xgran, const unsigned* seq, int* err, hipStream_t s) {
-    if (!wo_w13_supported(w0, g0) || !xgran || !seq || !err) return hipErrorNotSupported;
-    WoW13Args a{w0, g0, 0};
-    a.w.order_barrier = env_flag("LMRS_ORDER_BARRIER", 1); a.g.order_barrier = 0; a.g.chain_spread = env_flag("LMRS_CHAIN_SPREAD", 1);
-    a.w.gran = xgran; a.w.seq = seq; a.g.gran_in = xgran; a.g.seq = seq; a.g.err = err;
-    a.g.tag_sleep0 = env_flag("LMRS_WO_W13_TILES", 2); a.g.tag_sleep1 = env_flag("LMRS_WO_W13_SLEEP", 3);
-    a.n_wo = gemv_grid(a.w, PRO_QUANT, EPI_RESID);
-    const int n13 = gemv_grid(a.g, PRO_RMS_QUANT, EPI_SWIGLU);
-    size_t smem = gemv_smem(a.w, PRO_QUANT); const size_t s2 = gemv_smem(a.g, PRO_RMS_QUANT);
-    if (s2 > smem) smem = s2;
-    LMRS_LAUNCH_GRID((wo_w13_kernel<2048, 32, 2048, 16>), dim3(a.n_wo + n13), kBlock, smem, s, a);
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

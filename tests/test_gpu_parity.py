@@ -851,7 +851,6 @@ def test_merged_qkv_attention_launch_and_classifier_tail(L, monkeypatch, cfg, q)
     ref = orc.generate_greedy(prompt, n_new)
     m = L.Transformer(img)
     nl = m.args.n_layers
-    wo3 = (cfg, q) == ("mini-llama", S.Q8_0)                 # the shapes with a three-part class (LMRS_WO_MERGED=1, off by default: measured slower)
     merged = m.step_info(0)[0] == 4 * nl + 1 and m.step_info(200)[0] == 4 * nl + 1
     assert merged, f"{cfg}: the merged launch is not in use ({m.step_info(0)[0]} / {m.step_info(200)[0]} launches per step)"
     assert (m.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: default form"
@@ -859,17 +858,6 @@ def test_merged_qkv_attention_launch_and_classifier_tail(L, monkeypatch, cfg, q)
     m1 = L.Transformer(img)
     assert m1.step_info(0)[0] == 4 * nl + 1
     assert (m1.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: workgroup form"
-    if wo3:
-        monkeypatch.setenv("LMRS_QKV_ATT", "2"); monkeypatch.setenv("LMRS_WO_MERGED", "1")
-        m2 = L.Transformer(img)
-        assert m2.step_info(0)[0] == 3 * nl + 1 and m2.step_info(200)[0] == 4 * nl + 1
-        assert (m2.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: wo inside the merged launch (three-part form)"
-        monkeypatch.delenv("LMRS_WO_MERGED")
-        monkeypatch.setenv("LMRS_WO_W13", "1")                # wo + w1/w3 as one launch (the round-4 prototype of a persistent edge; off by default: slower)
-        m3 = L.Transformer(img)
-        assert m3.step_info(0)[0] == 3 * nl + 1 and m3.step_info(200)[0] == 3 * nl + 1
-        assert (m3.generate_greedy(prompt, n_new) == ref).all(), f"{cfg}: wo + w1/w3 as one launch"
-        monkeypatch.delenv("LMRS_WO_W13")
     monkeypatch.setenv("LMRS_QKV_ATT", "0"); monkeypatch.setenv("LMRS_CLS_TAIL", "0")
     m0 = L.Transformer(img)
     assert m0.step_info(0)[0] == 5 * nl + 2

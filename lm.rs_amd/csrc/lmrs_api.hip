@@ -1092,6 +1092,15 @@ static int launch_step(lmrs_ctx* c, uint32_t pos) {
         while (b < 3 && pos >= (1024u << b)) ++b;
         if (!c->att_S) HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->att_S), attention_split_scratch_floats(c->att_dim / (int)c->args.head_size, (int)c->args.seq_len) * 4));
     }
+    // profiling aid (LMRS_NO_GRAPH=1): the same launches enqueued one by one instead of a graph replay - rocprofv3 1.1's dispatch interceptor
+    // segfaults on the graph launches of every model but Llama-3.2-1B (profiles/README.md); token ids are the same either way
+    static const bool no_graph = getenv("LMRS_NO_GRAPH") != nullptr;
+    if (no_graph && !sharded && c->g_step) {
+        c->qa_mode = want_split ? 0 : qa_mode_for(c, pos); c->att_split_chunks = want_split ? 4 << b : 0; c->dbg_node = 0;
+        const int rc = enqueue_step(c);
+        c->qa_mode = 0; c->att_split_chunks = 0;
+        return rc;
+    }
     if (c->g_step) {
         if (want_split) {
             if (!c->g_step_long[b]) {
@@ -1433,7 +1442,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
         const uint32_t p = start_pos + (uint32_t)s;
         const int K = c->multi_k;
         const bool split_soon = c->att_split_pos > 0 && (int)(p + K - 1) >= c->att_split_pos;
-        if (K > 1 && c->g_step && !c->dbg && s + K <= steps && !split_soon && qa_mode_for(c, p) == qa_mode_for(c, p + K - 1)) {
+        if (K > 1 && c->g_step && !c->dbg && !getenv("LMRS_NO_GRAPH") && s + K <= steps && !split_soon && qa_mode_for(c, p) == qa_mode_for(c, p + K - 1)) {
             const int mode = qa_mode_for(c, p);
             if (!c->g_multi[mode]) {
                 c->qa_mode = mode;

@@ -869,12 +869,11 @@ __device__ __forceinline__ GemvArgs with_hot(const GemvArgs& a0, const float* xi
 #define LMRS_HOT_PARAMS const float* h_xin, const void* h_wq, const float* h_ws, const float* h_rms_w, const DevState* h_st, const unsigned* h_seq, float* h_out
 #define LMRS_HOT_OF(g) (g).xin, (g).wq, (g).ws, (g).rms_w, (g).st, (g).seq, (g).out
 
-// (A/B: -DLMRS_W2_MIN_WAVES=4 asks for two 512-thread workgroups per CU - at most 128 VGPRs - for the w2 classes)
-#ifdef LMRS_W2_MIN_WAVES
-#define LMRS_STATIC_BOUNDS(NTH_) __launch_bounds__(NTH_, (NTH_) == 512 ? LMRS_W2_MIN_WAVES : 1)
-#else
-#define LMRS_STATIC_BOUNDS(NTH_) __launch_bounds__(NTH_)
-#endif
+// The 512-thread classes (w2: a long quantise prologue over 8192 / 9216 values) ask for two workgroups per CU - four waves per SIMD, at most 128
+// VGPRs: 148 under the max-ilp scheduling strategy left the 384 workgroups of the 3072-wide models one per CU, in two rounds.  Same-box A/B
+// (profiles/r5_ab_w2_launch_bounds.txt): Llama-3.2-3B 975 -> 985 tok/s, Phi-3.5 860 -> 870, Llama-3.2-1B unchanged; a grid capped at 256 / 192
+// workgroups with a second pass instead: 981 / 978.
+#define LMRS_STATIC_BOUNDS(NTH_) __launch_bounds__(NTH_, (NTH_) == 512 ? 4 : 1)
 template <int N, int L, int PRO, int EPI, int NTH, bool Q4 = false>
 __global__ LMRS_STATIC_BOUNDS(NTH) void gemv_static_kernel(LMRS_HOT_PARAMS, const GemvArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1066,8 +1065,6 @@ int gemv_grid(const GemvArgs& a, int pro, int epi) {
     const int RB = (64 / sh.L) * ((sc.L ? sc.nt : kBlock) / 64);
     const int n_pass = (a.o + RB - 1) / RB;
     int cap = 4096;
-    static const int w2_cap = env_flag("LMRS_W2_GRID_CAP", 0);     // (A/B, round 5)
-    if (sc.L && sc.nt == 512 && w2_cap > 0) cap = w2_cap;
     if (epi == EPI_CLS) cap = 512;                         // classifier: persistent-style grid, prologue paid once per workgroup
     else if (sc.L && (epi == EPI_SWIGLU || epi == EPI_GELU)) {                             // w1w3: two passes per workgroup ...
         int k = 2;

@@ -57,6 +57,11 @@ def lib():
         L.lmrs_ref_op_expf.argtypes = [C.c_float]; L.lmrs_ref_op_expf.restype = C.c_float
         L.lmrs_ref_op_tanh_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double]; L.lmrs_ref_op_tanh_cast.restype = None
         L.lmrs_ref_rope_terms.argtypes = [C.POINTER(Args), u32, u32, f32p, f32p]; L.lmrs_ref_rope_terms.restype = None
+        L.lmrs_ref_random_u32.argtypes = [C.c_uint64]; L.lmrs_ref_random_u32.restype = u32
+        L.lmrs_ref_random_f32.argtypes = [C.c_uint64]; L.lmrs_ref_random_f32.restype = C.c_float
+        L.lmrs_ref_sampler_new.argtypes = [u32, C.c_float, C.c_float, C.c_uint64]; L.lmrs_ref_sampler_new.restype = vp
+        L.lmrs_ref_sampler_free.argtypes = [vp]; L.lmrs_ref_sampler_free.restype = None
+        L.lmrs_ref_sampler_sample.argtypes = [vp, vp]; L.lmrs_ref_sampler_sample.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -171,6 +176,36 @@ def tanh_cast(x, c=1.0) -> np.ndarray:
     y = np.empty_like(x)
     lib().lmrs_ref_op_tanh_cast(_p(x), _p(y), x.size, float(c))
     return y
+
+
+def random_u32(state: int) -> int:
+    return int(lib().lmrs_ref_random_u32(state & ((1 << 64) - 1)))
+
+
+def random_f32(state: int) -> float:
+    return float(lib().lmrs_ref_random_f32(state & ((1 << 64) - 1)))
+
+
+class Sampler:
+    """Mirror of lmrs::sampler::Sampler (src/sampler.rs:10-129) over the oracle: the candidate vector persists across calls."""
+
+    def __init__(self, vocab_size: int, temperature: float, top_p: float, seed: int):
+        self.h = lib().lmrs_ref_sampler_new(vocab_size, temperature, top_p, seed & ((1 << 64) - 1))
+        if not self.h:
+            raise RuntimeError("lmrs_ref_sampler_new failed")
+        self.vocab_size = vocab_size
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lmrs_ref_sampler_free(self.h); self.h = None
+
+    def sample(self, logits: np.ndarray) -> int:
+        """logits: float32[vocab_size], scaled and soft-maxed IN PLACE when temperature != 0 (sampler.rs:115-117)."""
+        assert logits.dtype == np.float32 and logits.size == self.vocab_size and logits.flags.c_contiguous
+        t = int(lib().lmrs_ref_sampler_sample(self.h, _p(logits)))
+        if t < 0:
+            raise RuntimeError("sample_topp: no candidate above the cutoff (the reference panics)")
+        return t
 
 
 def threads() -> int:

@@ -48,15 +48,19 @@ def test_expf_matches_host_libm(L):
 
 @pytest.mark.parametrize("n,temperature", [(64, 1.0), (1000, 0.7), (4102, 1.3), (128256, 0.8), (32064, 2.0)])
 def test_sampler_on_the_device(L, n, temperature):
-    """Sampler::sample (sampler.rs:109-129; temperature != 0, sample_mult) on the device against the host sampler (lmrs_text.cpp, itself
-    checked against the second transcription in tests/text_ref.py): the probabilities the logits are turned into bit for bit - the
-    sequential softmax sum over the whole vocabulary runs lane by lane in one wave - and the same draw for random numbers across the
-    range, the first / last term and block-of-64 boundaries of the running cdf included."""
+    """Sampler::sample (sampler.rs:109-129; temperature != 0, sample_mult) on the device against the ORACLE's sampler
+    (oracle/lmrs_oracle.c lmrs_ref_sampler_*; the product's host sampler, lmrs_text.cpp, is checked against it as well): the
+    probabilities the logits are turned into bit for bit - the sequential softmax sum over the whole vocabulary - and the same draw
+    for random numbers across the range, the first / last term and block-of-64 boundaries of the running cdf included."""
     rng = np.random.default_rng(n)
     logits = (rng.standard_normal(n) * 3).astype(np.float32)
-    host = L.Sampler(n, temperature, 1.0, 1)                      # top_p = 1: sample_mult
-    _, _, _, rnd0 = host.info()
-    want_probs = logits.copy(); want_tok = host.sample(want_probs)
+    orc = O.Sampler(n, temperature, 1.0, 1)                       # top_p = 1: sample_mult
+    host = L.Sampler(n, temperature, 1.0, 1)
+    rnd0 = O.random_f32(1)
+    assert np.float32(host.info()[3]) == np.float32(rnd0)
+    want_probs = logits.copy(); want_tok = orc.sample(want_probs)
+    host_probs = logits.copy(); assert host.sample(host_probs) == want_tok
+    assert_bit_equal(host_probs, want_probs, "host sampler's softmax against the oracle's")
     tok, probs = L.sample_mult(logits, temperature, rnd0)
     assert_bit_equal(probs, want_probs, f"softmax of {n} logits at temperature {temperature}")
     assert tok == want_tok
@@ -71,35 +75,41 @@ def test_sampler_on_the_device(L, n, temperature):
         assert t2 == draw(r), f"n={n} r={r}: device {t2}, host {draw(r)}"
 
 
-def test_forward_sample_matches_forward_plus_host_sampler(L):
-    """lmrs_forward_sample (logits stay in HBM) against lmrs_forward + lmrs_sampler_sample: greedy, temperature sampling, top-p
-    (scaling, softmax and the cutoff filter on the device, the candidates' sort on the host)."""
+def test_forward_sample_matches_the_oracle(L):
+    """lmrs_forward_sample (logits stay in HBM) and lmrs_forward + lmrs_sampler_sample (the host route) against the ORACLE's
+    forward + the oracle's sampler (oracle/lmrs_oracle.c): greedy, temperature sampling, top-p (scaling, softmax and the cutoff
+    filter on the device, the candidates' sort on the host).  Three independent runs, one persistent sampler each."""
     img = S.build_image("mini-llama", S.Q8_0, seed=77)
     prompt = S.prompt_tokens("mini-llama", 4, 77)
     for temperature, top_p, steps in [(0.0, 0.9, 12), (0.8, 1.0, 12), (1.5, 0.0, 12), (0.7, 0.9, 200), (0.05, 0.5, 60), (3.0, 0.999, 40)]:
-        a = L.Transformer(img); b = L.Transformer(img)
-        sa = L.Sampler(a.args.vocab_size, temperature, top_p, 12345); sb = L.Sampler(b.args.vocab_size, temperature, top_p, 12345)
-        ta = tb = None
+        a = L.Transformer(img); b = L.Transformer(img); o = O.Oracle(img)
+        V = a.args.vocab_size
+        sa = L.Sampler(V, temperature, top_p, 12345); sb = L.Sampler(V, temperature, top_p, 12345); so = O.Sampler(V, temperature, top_p, 12345)
+        ta = tb = to = None
         for pos in range(steps):
-            t = int(prompt[pos]) if pos < len(prompt) else ta
+            t = int(prompt[pos]) if pos < len(prompt) else to
             ta = a.forward_sample(t, pos, sa)
             tb = sb.sample(b.forward(t, pos))
-            assert ta == tb, f"temperature {temperature}, top_p {top_p}, pos {pos}: device {ta}, host {tb}"
+            to = so.sample(o.forward(t, pos).copy())
+            assert ta == to, f"temperature {temperature}, top_p {top_p}, pos {pos}: device route {ta}, oracle {to}"
+            assert tb == to, f"temperature {temperature}, top_p {top_p}, pos {pos}: host route {tb}, oracle {to}"
 
 
 def test_topp_filter_on_peaked_and_flat_distributions(L):
     """sample_topp's device front half on the real vocabulary size: a peaked distribution (a handful of candidates cross to the host), a flat
     one (more than half the vocabulary passes the cutoff: the probabilities are copied instead) and stale candidates of an earlier, wider
-    call still in the sampler's persistent vector - each against the host sampler on the same logits, through the classifier-less op path."""
+    call still in the sampler's persistent vector - the device route and the host route each against the ORACLE's sampler on the oracle's logits."""
     rng = np.random.default_rng(5)
     img = S.build_image("mini-llama", S.Q8_0, seed=78)
-    a = L.Transformer(img); b = L.Transformer(img)
+    a = L.Transformer(img); b = L.Transformer(img); o = O.Oracle(img)
     V = a.args.vocab_size
     for temperature, top_p in [(0.7, 0.9), (1.0, 0.3)]:
-        sa = L.Sampler(V, temperature, top_p, 777); sb = L.Sampler(V, temperature, top_p, 777)
-        for pos in range(30):                                  # one pair of samplers across calls: the persistent-vector quirk is exercised
+        sa = L.Sampler(V, temperature, top_p, 777); sb = L.Sampler(V, temperature, top_p, 777); so = O.Sampler(V, temperature, top_p, 777)
+        for pos in range(30):                                  # one sampler per route across calls: the persistent-vector quirk is exercised
             t = int(rng.integers(0, V))
-            assert a.forward_sample(t, pos, sa) == sb.sample(b.forward(t, pos)), (temperature, top_p, pos)
+            want = so.sample(o.forward(t, pos).copy())
+            assert a.forward_sample(t, pos, sa) == want, (temperature, top_p, pos)
+            assert sb.sample(b.forward(t, pos)) == want, (temperature, top_p, pos)
 
 
 @pytest.mark.parametrize("c", [1.0, 0.7978845608028654])

@@ -7,6 +7,7 @@ import struct
 import numpy as np
 import pytest
 
+import oracle_lib as O
 import text_ref as R
 
 
@@ -108,18 +109,45 @@ def test_random_numbers():
 @pytest.mark.parametrize("temperature,top_p,seed", [(0.0, 0.9, 1), (0.7, 0.9, 42), (0.7, 0.9, 1727000000123), (1.3, 0.5, 7), (0.7, 1.0, 42), (0.7, 0.0, 99), (0.2, 0.95, 3)])
 def test_sampler_matches_the_second_transcription(L, temperature, top_p, seed):
     """Sampler::sample over several calls of ONE sampler: the candidate vector keeps stale entries between calls and is sorted as a
-    whole (sampler.rs:81), and the random number is the same on every call (:119) - both are part of the reference's behaviour."""
+    whole (sampler.rs:81), and the random number is the same on every call (:119) - both are part of the reference's behaviour.
+    Three implementations: the product's host sampler (lmrs_text.cpp), the ORACLE's (oracle/lmrs_oracle.c lmrs_ref_sampler_*: the
+    checker of the GPU tier's sampler tests) and the pure-Python transcription."""
     V = 1500
-    dev = L.Sampler(V, temperature, top_p, seed); ref = R.Sampler(V, temperature, top_p, seed)
+    dev = L.Sampler(V, temperature, top_p, seed); orc = O.Sampler(V, temperature, top_p, seed); ref = R.Sampler(V, temperature, top_p, seed)
     rng = np.random.default_rng(seed % 1000)
     for call in range(5):
         lg = (rng.standard_normal(V) * (3.0 if call % 2 else 0.8)).astype(np.float32)
         if call == 3:
             lg[17] = lg.max() + 9.0                                # a dominant token: top-p keeps a single candidate
-        a = lg.copy(); b = [np.float32(v) for v in lg]
-        t_dev = dev.sample(a); t_ref = ref.sample(b)
-        assert t_dev == t_ref, (call, t_dev, t_ref)
+        a = lg.copy(); o = lg.copy(); b = [np.float32(v) for v in lg]
+        t_dev = dev.sample(a); t_orc = orc.sample(o); t_ref = ref.sample(b)
+        assert t_dev == t_ref == t_orc, (call, t_dev, t_orc, t_ref)
         assert (a.view(np.uint32) == np.array(b, np.float32).view(np.uint32)).all(), f"call {call}: logits after sample() differ"
+        assert (o.view(np.uint32) == np.array(b, np.float32).view(np.uint32)).all(), f"call {call}: the oracle's logits after sample() differ"
+
+
+def test_oracle_sampler_on_the_real_vocabulary_size():
+    """The oracle's sampler against the product's host sampler at 128 256 entries over many calls of one sampler each: wide calls
+    followed by narrow ones (stale candidates above the new ones' tail), ties (equal probabilities keep index order: the sort is stable),
+    the same random number every call."""
+    import lmrs_amd as L
+    V = 128256
+    rng = np.random.default_rng(3)
+    for temperature, top_p in [(0.7, 0.9), (1.0, 0.3), (0.9, 1.0)]:
+        a = L.Sampler(V, temperature, top_p, 20240925); b = O.Sampler(V, temperature, top_p, 20240925)
+        for call in range(6):
+            lg = (rng.standard_normal(V) * [0.3, 6.0, 25.0][call % 3]).astype(np.float32)
+            if call == 4:
+                lg[1000:1040] = lg.max() + 1.0                     # forty equal maxima
+            x = lg.copy(); y = lg.copy()
+            assert a.sample(x) == b.sample(y), (temperature, top_p, call)
+            assert (x.view(np.uint32) == y.view(np.uint32)).all()
+
+
+def test_oracle_random_numbers():
+    for seed in (0, 1, 42, 1234567, 1727000000123, (1 << 64) - 1):
+        assert O.random_u32(seed) == R.random_u32(seed)
+        assert np.float32(O.random_f32(seed)) == R.random_f32(seed)
 
 
 def test_topp_from_candidate_pairs_equals_the_whole_sampler(L):

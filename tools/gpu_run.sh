@@ -5,7 +5,8 @@
 #   tests      pytest -m gpu
 #   bench      the driver's bench invocation (20 steps) and the 128-step default
 #   models     bench lines of the four BASELINE models (64 steps)
-#   stats M Q  rocprofv3 --kernel-trace --stats of a 64-step bench of model M, qtype Q (one step per graph launch: see profiles/README.md)
+#   stats M Q  rocprofv3 --kernel-trace --stats of a 64-step bench of model M, qtype Q (PROF_ENV, default LMRS_NO_GRAPH=1: the step's launches
+#              enqueued one by one - rocprofv3 1.1 segfaults on the graph launches of every model but Llama-3.2-1B, see profiles/README.md)
 #   pmc M Q    FETCH_SIZE / WRITE_SIZE passes of the same (separate runs, kernel-trace only)
 #   prefill N  fill_kv_cache(N) rate + rocprofv3 kernel statistics
 #   vision     CLIP tower rate + rocprofv3 kernel statistics
@@ -29,12 +30,12 @@ while [ $# -gt 0 ]; do
         timeout 400 python bench.py --model phi-3.5 --steps 64 > $OUT/bench_phi35.json 2>> $OUT/bench.err;;
     stats) M=$1; Q=$2; shift 2; N=$(short $M)_$Q
         rm -rf $OUT/st_$N
-        LMRS_STEPS_PER_GRAPH=${STEPS_PER_GRAPH:-1} timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$N -- python bench.py --model $M --qtype $Q --steps 64 --cpu-steps 0 > $OUT/stats_$N.log 2>&1
+        env ${PROF_ENV:-LMRS_NO_GRAPH=1} timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$N -- python bench.py --model $M --qtype $Q --steps 64 --cpu-steps 0 > $OUT/stats_$N.log 2>&1
         echo "stats $N rc $?"; cp $(ls $OUT/st_$N/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats_$N.csv 2>/dev/null; rm -rf $OUT/st_$N;;
     pmc) M=$1; Q=$2; shift 2; N=$(short $M)_$Q
         for c in FETCH_SIZE WRITE_SIZE; do
             rm -rf $OUT/pmc_${N}_$c
-            LMRS_STEPS_PER_GRAPH=1 timeout -k 5 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${N}_$c -- python bench.py --model $M --qtype $Q --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_${N}_$c.log 2>&1
+            env ${PROF_ENV:-LMRS_NO_GRAPH=1} timeout -k 5 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${N}_$c -- python bench.py --model $M --qtype $Q --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_${N}_$c.log 2>&1
             echo "pmc $N $c rc $?"
         done
         f=$(ls $OUT/pmc_${N}_FETCH_SIZE/*/*counter_collection.csv 2>/dev/null | head -1); w=$(ls $OUT/pmc_${N}_WRITE_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)

@@ -163,8 +163,9 @@ int lmrs_op_expf(int device, float* y, const float* x, size_t n);
 /* y = (float)tanh(c * (double)x): f64::tanh as the reference calls it for Gemma's soft-caps (transformer.rs:520-522, 377-379; c = 1) and
  * the tanh-GELU (transformer.rs:614; c = 0.7978845608028654) - the device's f64 tanh, for comparison with the host libm (oracle/tanh_check.c). */
 int lmrs_op_tanh_cast(int device, float* y, const float* x, size_t n, double c);
-/* Sampler::sample (sampler.rs:109-129) for temperature != 0 and sample_mult, on the device, on caller-supplied logits: they are scaled and
- * softmax-ed IN PLACE (as the reference does to the slice) and *token = the draw for the random number rnd.  Unit parity for lmrs_forward_sample. */
+/* Sampler::sample (sampler.rs:109-129) for temperature != 0 and sample_mult on caller-supplied logits through lmrs_forward_sample's route (scaling,
+ * maximum and exponentials on the device, the two sequential chains on the host): they are scaled and softmax-ed IN PLACE (as the reference does
+ * to the slice) and *token = the draw for the random number rnd.  Unit parity for lmrs_forward_sample. */
 int lmrs_op_sample_mult(int device, float* logits, size_t n, float temperature, float rnd, uint32_t* token);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------
@@ -277,14 +278,19 @@ int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
  * elsewhere (lmrs_forward_sample runs them on the device): pairs = n0 candidates {f32 prob, u32 index} with
  * prob >= (1 - top_p) / (vocab_size - 1), in index order - what :74-80 leaves in probindex[0 .. n0). */
 int lmrs_sampler_topp_pairs(lmrs_sampler* s, const void* pairs, size_t n0, uint32_t* next);
+/* Sampler::sample from the softmax's exponentials on (functional.rs:134-139, then sampler.rs:119-128): exps[i] = exp(logits[i] / temperature - max)
+ * were formed elsewhere (lmrs_forward_sample forms them on the device); the sequential sum, the division, and sample_mult / sample_topp run here.
+ * exps become the probabilities in place.  Same token and probabilities as lmrs_sampler_sample on the logits. */
+int lmrs_sampler_sample_exps(lmrs_sampler* s, float* exps, uint32_t* next);
 int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd);   /* rnd = random_f32(seed), the same on every call (:119) */
-/* Transformer::forward (src/transformer.rs:316) followed by Sampler::sample (src/sampler.rs:109-129) with the logits staying in HBM:
- * temperature 0 -> the argmax fused into the decode step; temperature != 0 with top_p outside (0, 1) -> temperature scaling, softmax in
- * place and sample_mult ON THE DEVICE (sample_*_kernel: the reference's sequential sums run lane by lane in one wave); top_p inside (0, 1)
- * (sample_topp, :67-106 - the reference's default, chat.rs:28-31) -> scaling, softmax and the cutoff filter on the device, only the
- * surviving (prob, index) pairs cross to the host, where lmrs_sampler_topp_pairs runs the stable sort over the sampler's persistent
- * candidate vector, the cumulative cut and the draw (when more than half the vocabulary survives - a nearly flat distribution - the
- * probabilities are copied instead).  Same token as lmrs_forward + lmrs_sampler_sample in every case.  One-GPU contexts. */
+/* Transformer::forward (src/transformer.rs:316) followed by Sampler::sample (src/sampler.rs:109-129) without the host ever touching the
+ * logits: temperature 0 -> the argmax fused into the decode step; temperature != 0 -> the parallel part of the sampler on the device -
+ * logits / temperature (:115), the maximum and exp(x - max) (functional.rs:126-133) - then the vocab_size exponentials cross to the host,
+ * where lmrs_sampler_sample_exps runs the reference's sequential chains (the softmax sum, the running cdf) and sample_mult (:43-55) or
+ * sample_topp (:67-106, the reference's default, chat.rs:28-31) over the sampler's persistent candidate vector.  Round 4 ran the chains
+ * on the device as well (one wave, lane by lane): 1106 us per token against 1020 for the host sampler on copied logits - a dependent f32
+ * add is ~1 ns on a host core and ~2.5 ns on one GPU lane; this split was measured at profiles/r5_sampler_rate.txt.  Same token as
+ * lmrs_forward + lmrs_sampler_sample in every case.  One-GPU contexts (sharded ones copy the gathered logits). */
 int lmrs_forward_sample(lmrs_ctx* ctx, uint32_t token, uint32_t pos, lmrs_sampler* sampler, uint32_t* next);
 
 #ifdef __cplusplus

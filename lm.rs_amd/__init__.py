@@ -32,7 +32,7 @@ EXPORTS = [
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
     "lmrs_tokenizer_create", "lmrs_tokenizer_destroy", "lmrs_tokenizer_info", "lmrs_tokenizer_encode", "lmrs_tokenizer_decode",
-    "lmrs_sampler_create", "lmrs_sampler_destroy", "lmrs_sampler_sample", "lmrs_sampler_topp_pairs",
+    "lmrs_sampler_create", "lmrs_sampler_destroy", "lmrs_sampler_sample", "lmrs_sampler_sample_exps", "lmrs_sampler_topp_pairs",
 ]
 
 
@@ -121,6 +121,7 @@ def lib():
         L.lmrs_sampler_destroy.argtypes = [vp]; L.lmrs_sampler_destroy.restype = None
         L.lmrs_sampler_sample.argtypes = [vp, vp, C.POINTER(u32)]
         L.lmrs_sampler_topp_pairs.argtypes = [vp, vp, sz, C.POINTER(u32)]
+        L.lmrs_sampler_sample_exps.argtypes = [vp, vp, C.POINTER(u32)]
         L.lmrs_sampler_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lmrs_forward_sample.argtypes = [vp, u32, u32, vp, C.POINTER(u32)]
         L.lmrs_op_sample_mult.argtypes = [C.c_int, vp, sz, C.c_float, C.c_float, C.POINTER(u32)]
@@ -507,6 +508,13 @@ class Sampler:
         assert logits.dtype == np.float32 and logits.flags.c_contiguous and logits.size >= self.vocab_size
         nxt = C.c_uint32()
         _chk(lib().lmrs_sampler_sample(self._h, _p(logits), C.byref(nxt)))
+        return nxt.value
+
+    def sample_exps(self, exps: np.ndarray) -> int:
+        """Sampler::sample from the softmax's exponentials on (lmrs_sampler_sample_exps): exps = exp(logits / temperature - max), turned into the probabilities in place"""
+        assert exps.dtype == np.float32 and exps.flags.c_contiguous and exps.size >= self.vocab_size
+        nxt = C.c_uint32()
+        _chk(lib().lmrs_sampler_sample_exps(self._h, _p(exps), C.byref(nxt)))
         return nxt.value
 
     def topp_pairs(self, prob: np.ndarray, index: np.ndarray) -> int:

@@ -98,7 +98,6 @@ struct lmrs_ctx {
     bool p2p = false, p2p_ready = false; char* xarena = nullptr; size_t xarena_bytes = 0; char* peer_base[kMaxWorld] = {};
     unsigned *xflags = nullptr, *xseq = nullptr; int* xerr = nullptr; int ex_slot = 0; bool xarena_is_ipc[kMaxWorld] = {};
     double last_fill_ms = -1.0;                    // device time of the last batched fill_kv_cache between its upload and its download (lmrs_last_fill_ms)
-    void* topp_pairs = nullptr;                    // lmrs_forward_sample, top-p: vocab_size (prob, index) pairs + the filter's counts (allocated on first use)
     bool err_queued = false;                       // the error word's copy to h_err rides in front of the call's own synchronise (queue_err)
     int* err = nullptr; int* h_err = nullptr;      // error word of the bounded in-launch waits (merged qkv + attention launch, classifier tail)
     // ---- merged qkv + attention launch (launch_qkv_attn): per-layer {value, tag} granules, the step sequence number the tags are
@@ -1060,7 +1059,6 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->g_step) (void)hipGraphExecDestroy(c->g_step);
     for (auto& g : c->g_step_long) if (g) (void)hipGraphExecDestroy(g);
     if (c->att_S) (void)hipFree(c->att_S);
-    if (c->topp_pairs) (void)hipFree(c->topp_pairs);
     if (c->g_layers) (void)hipGraphExecDestroy(c->g_layers);
     for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : c->g_multi) if (g) (void)hipGraphExecDestroy(g);
@@ -1177,7 +1175,7 @@ extern "C" int lmrs_forward_argmax(lmrs_ctx* c, uint32_t token, uint32_t pos, ui
 struct lmrs_sampler;
 extern "C" int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd);
 extern "C" int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
-extern "C" int lmrs_sampler_topp_pairs(lmrs_sampler* s, const void* pairs, size_t n0, uint32_t* next);
+extern "C" int lmrs_sampler_sample_exps(lmrs_sampler* s, float* exps, uint32_t* next);
 extern "C" int lmrs_forward_sample(lmrs_ctx* c, uint32_t token, uint32_t pos, lmrs_sampler* sampler, uint32_t* next) {
     if (!c || !sampler || !next) return fail("NULL argument");
     uint32_t vs = 0; float temp = 0, top_p = 0, rnd = 0;
@@ -1189,47 +1187,17 @@ extern "C" int lmrs_forward_sample(lmrs_ctx* c, uint32_t token, uint32_t pos, lm
         if (lmrs_forward(c, token, pos, &lg)) return -1;
         return lmrs_sampler_sample(sampler, lg, next);
     }
-    if (top_p > 0.0f && top_p < 1.0f) {
-        // sample_topp (sampler.rs:67-106): scaling, softmax and the cutoff filter on the device; the candidates - a handful for a peaked
-        // distribution - go to the host as (prob, index) pairs in index order, the sort over the sampler's persistent vector runs there
-        const size_t n = c->args.vocab_size;
-        if (!c->topp_pairs) HIP_OK(hipMalloc(&c->topp_pairs, n * 8 + 256 * 4 + 16));
-        unsigned* counts = reinterpret_cast<unsigned*>(static_cast<char*>(c->topp_pairs) + n * 8);
-        unsigned* n0d = counts + 256;
-        if (step_once(c, token, pos)) return -1;
-        SampleArgs sa{c->logits, (int)n, temp, rnd, c->part_val, c->part_val + kSampleGrid + 1, c->tokens + c->args.seq_len + 4};
-        const float cutoff = (1.0f - top_p) / (float)(n - 1);                             // :71, f32 as in the reference
-        HIP_OK(launch_sample_topp_filter(sa, cutoff, c->topp_pairs, n0d, counts, c->stream));
-        // one transfer for the usual case: the count and the first kToppEager pairs land together in the pinned logits buffer
-        constexpr size_t kToppEager = 2048;
-        const size_t eager = std::min(kToppEager, n / 2);                                 // (the pinned buffer holds vocab_size floats = vocab_size / 2 pairs)
-        uint32_t* hn0 = c->h_tok + 2;
-        HIP_OK(hipMemcpyAsync(hn0, n0d, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipMemcpyAsync(c->h_logits, c->topp_pairs, eager * 8, hipMemcpyDeviceToHost, c->stream));
-        if (queue_err(c)) return -1;
-        HIP_OK(hipStreamSynchronize(c->stream));
-        if (check_err(c)) return -1;
-        const size_t n0 = *hn0;
-        if (n0 > n / 2) {                                  // nearly flat: the probability vector is the smaller message (and h_logits holds exactly that)
-            HIP_OK(hipMemcpy(c->h_logits, c->logits, n * 4, hipMemcpyDeviceToHost));
-            std::vector<float> pairs(2 * n0);
-            size_t k = 0;
-            for (size_t i = 0; i < n && k < n0; ++i)
-                if (c->h_logits[i] >= cutoff) { pairs[2 * k] = c->h_logits[i]; uint32_t ix = (uint32_t)i; memcpy(&pairs[2 * k + 1], &ix, 4); ++k; }
-            return lmrs_sampler_topp_pairs(sampler, pairs.data(), k, next);
-        }
-        if (n0 > eager) HIP_OK(hipMemcpy(reinterpret_cast<char*>(c->h_logits) + eager * 8, static_cast<char*>(c->topp_pairs) + eager * 8, (n0 - eager) * 8, hipMemcpyDeviceToHost));
-        return lmrs_sampler_topp_pairs(sampler, c->h_logits, n0, next);
-    }
+    // temperature != 0: the parallel part on the device (scaling, maximum, exponentials), the sequential chains on the host (lmrs_sampler_sample_exps)
+    (void)top_p; (void)rnd;
     if (step_once(c, token, pos)) return -1;
-    SampleArgs sa{c->logits, (int)c->args.vocab_size, temp, rnd, c->part_val, c->part_val + kSampleGrid + 1, c->tokens + c->args.seq_len + 4};   // (scratch: the argmax partials; a spare token slot)
-    HIP_OK(launch_sample_mult(sa, c->stream));
-    HIP_OK(hipMemcpyAsync(c->h_tok + 1, sa.out_token, 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t n = c->args.vocab_size;
+    SampleArgs sa{c->logits, (int)n, temp, c->part_val};                                  // (scratch: the argmax partials)
+    HIP_OK(launch_sample_exps(sa, c->stream));
+    HIP_OK(hipMemcpyAsync(c->h_logits, c->logits, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (queue_err(c)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
-    *next = c->h_tok[1];
-    return 0;
+    return lmrs_sampler_sample_exps(sampler, c->h_logits, next);
 }
 
 extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, size_t n, float* out) {
@@ -1792,13 +1760,18 @@ extern "C" int lmrs_op_classifier_argmax(int device, const float* x, const float
 extern "C" int lmrs_op_sample_mult(int device, float* logits, size_t n, float temperature, float rnd, uint32_t* token) {
     if (op_begin(device)) return -1;
     if (!logits || !token || n == 0 || temperature == 0.0f) return fail("bad argument (temperature 0 is sample_argmax: lmrs_op_classifier_argmax)");
-    Scratch S; void *dl = S.get(n * 4), *dp = S.get((kSampleGrid + 8) * 4), *dt = S.get(16);
-    if (!dt) return fail("hipMalloc failed");
+    Scratch S; void *dl = S.get(n * 4), *dp = S.get((kSampleGrid + 8) * 4);
+    if (!dp) return fail("hipMalloc failed");
     HIP_OK(hipMemcpy(dl, logits, n * 4, hipMemcpyHostToDevice));
-    SampleArgs sa{static_cast<float*>(dl), (int)n, temperature, rnd, static_cast<float*>(dp), static_cast<float*>(dp) + kSampleGrid + 1, static_cast<uint32_t*>(dt)};
-    HIP_OK(launch_sample_mult(sa, nullptr));
-    HIP_OK(hipMemcpy(token, dt, 4, hipMemcpyDeviceToHost));
+    SampleArgs sa{static_cast<float*>(dl), (int)n, temperature, static_cast<float*>(dp)};
+    HIP_OK(launch_sample_exps(sa, nullptr));
     HIP_OK(hipMemcpy(logits, dl, n * 4, hipMemcpyDeviceToHost));
+    // the chains, as lmrs_sampler_sample_exps runs them for a sample_mult sampler (functional.rs:134-139, sampler.rs:43-55), with the caller's random number
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; ++i) sum = sum + logits[i];
+    for (size_t i = 0; i < n; ++i) logits[i] = logits[i] / sum;
+    float cdf = 0.0f; *token = (uint32_t)(n - 1);
+    for (size_t i = 0; i < n; ++i) { cdf = cdf + logits[i]; if (rnd < cdf) { *token = (uint32_t)i; break; } }
     return 0;
 }
 

@@ -127,14 +127,12 @@ hipError_t launch_addnorm(float* x, const float* delta, const float* w, int n, f
 hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s);
 hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint32_t* tokens, int n_tok, int dim, float* out, hipStream_t st);
 
-// ---- Sampler::sample on the device (sampler.rs:109-129 for temperature != 0 and top_p outside (0, 1): temperature scaling, softmax
-// in place, sample_mult).  scratch: n_part floats of per-workgroup maxima + 1 float (the sum); *out_token receives the draw.
-struct SampleArgs { float* logits; int n; float temperature; float rnd; float* part; float* sum; uint32_t* out_token; };
+// ---- the parallel part of Sampler::sample (sampler.rs:109-129, temperature != 0): logits[i] /= temperature (:115), the maximum, and
+// logits[i] = exp(logits[i] - max) (functional.rs:126-133) in place.  The sequential chains behind it run on the host (lmrs_sampler_sample_exps).
+// part: kSampleGrid + 1 floats of scratch (per-workgroup maxima, x[0]).
+struct SampleArgs { float* logits; int n; float temperature; float* part; };
 constexpr int kSampleGrid = 256;
-hipError_t launch_sample_mult(const SampleArgs& a, hipStream_t s);
-// ... and sample_topp's front half (sampler.rs:67-80): temperature scaling, softmax, then the candidates p >= cutoff as (prob, index)
-// pairs in index order -> pairs[0 .. *n0) (room for a.n pairs); counts: kSampleGrid unsigned of scratch.  a.rnd / a.out_token unused.
-hipError_t launch_sample_topp_filter(const SampleArgs& a, float cutoff, void* pairs, unsigned* n0, unsigned* counts, hipStream_t s);
+hipError_t launch_sample_exps(const SampleArgs& a, hipStream_t s);
 
 // thin kernels over the same device functions, for the lmrs_op_* unit-parity entry points
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st);

@@ -2068,15 +2068,12 @@ hipError_t launch_argmax_final(const ArgmaxArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sampler::sample on the device (sampler.rs:109-129, the temperature != 0 branch with sample_mult :43-55): the logits never leave HBM.
+// The parallel part of Sampler::sample (sampler.rs:109-129, temperature != 0) on the device:
 //   1. logits[i] /= temperature (:115), per-workgroup maxima                                   [grid]
 //   2. logits[i] = exp(logits[i] - max) (functional.rs:126-133: max starts at x[0], strict >)   [grid]
-//   3. sum: the reference's ONE sequential chain over all n exponentials (functional.rs:134) - a single wave, 64 terms per
-//      register, added lane by lane through the add's DPP operand (wave_serial_sum): one dependent add per term, 0.2 ms for 128 256
-//   4. logits[i] /= sum (:137-139)                                                               [grid]
-//   5. sample_mult: the running cdf in the same way, block of 64 by block of 64, until it passes the random number; the crossing is
-//      then located term by term inside that block (the cdf never decreases: probabilities are >= 0)
-// Bit-identical to the host sampler (lmrs_text.cpp) by construction: same operations, same order.
+// The softmax sum (one sequential chain over all n exponentials, functional.rs:134), the division and sample_mult's running cdf /
+// sample_topp's sort run on the host (lmrs_sampler_sample_exps, lmrs_text.cpp): round 4 ran the chains here in one wave, lane by lane
+// through the add's DPP operand (~2.5 ns per term against ~1 ns on a host core) and measured it slower than copying the logits.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void sample_scale_max_kernel(const SampleArgs a) {
     __shared__ float red[kBlock / 64];
@@ -2104,117 +2101,10 @@ __global__ __launch_bounds__(kBlock) void sample_exp_kernel(const SampleArgs a, 
     if (!(x0 == x0)) mx = x0;                                    // max_val starts at x[0] and only moves on a strict `>`: a NaN there stays
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) a.logits[i] = expf_glibc(a.logits[i] - mx);
 }
-// 64 terms per register, 8 registers in flight; terms past n are +0.0 (exact no-ops on a running sum that starts at +0.0)
-__device__ __forceinline__ float sample_block(const float* x, int i0, int n, int lane) { const int i = i0 + lane; return i < n ? x[i] : 0.0f; }
-__global__ __launch_bounds__(64) void sample_sum_kernel(const SampleArgs a) {
-    const int lane = threadIdx.x;
-    float sum = 0.0f;
-    for (int i0 = 0; i0 < a.n; i0 += 512) {
-        float e[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) e[u] = sample_block(a.logits, i0 + 64 * u, a.n, lane);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (i0 + 64 * u < a.n) { const int left = a.n - (i0 + 64 * u); sum = wave_serial_sum(sum, e[u], left >= 64 ? 4 : (left + 15) >> 4); }   // wave-uniform
-    }
-    if (lane == 0) *a.sum = sum;
-}
-__global__ __launch_bounds__(kBlock) void sample_div_kernel(const SampleArgs a) {
-    const float sum = *a.sum;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) a.logits[i] = a.logits[i] / sum;
-}
-__global__ __launch_bounds__(64) void sample_pick_kernel(const SampleArgs a) {
-    const int lane = threadIdx.x;
-    float cdf = 0.0f;
-    uint32_t pick = (uint32_t)(a.n - 1);                         // sampler.rs:54: rounding left the cdf below the random number
-    bool found = false;
-    for (int i0 = 0; i0 < a.n && !found; i0 += 512) {
-        float p[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = sample_block(a.logits, i0 + 64 * u, a.n, lane);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (!found && i0 + 64 * u < a.n) {                   // wave-uniform
-                const int left = a.n - (i0 + 64 * u);
-                const float before = cdf;
-                cdf = wave_serial_sum(cdf, p[u], left >= 64 ? 4 : (left + 15) >> 4);
-                if (a.rnd < cdf) {                               // the crossing is inside this block: the same adds once more, term by term
-                    float c = before;
-                    for (int l = 0; l < 64 && i0 + 64 * u + l < a.n; ++l) {
-                        c = c + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, p[u]), l));
-                        if (a.rnd < c) { pick = (uint32_t)(i0 + 64 * u + l); break; }
-                    }
-                    found = true;
-                }
-            }
-        }
-    }
-    if (lane == 0) *a.out_token = pick;
-}
-// sample_topp's filter (sampler.rs:74-80) on the device: the candidates `p >= cutoff` leave as (prob, index) pairs IN INDEX ORDER - the
-// order the reference's loop appends them in, which its stable sort preserves among equal probabilities - so that only they cross to
-// the host, not 513 KB of probabilities.  Two launches over contiguous chunks: counts per workgroup, then every workgroup's offset
-// (the counts before it) + an order-preserving scan of its own chunk.
-__global__ __launch_bounds__(kBlock) void topp_count_kernel(const float* __restrict__ p, int n, float cutoff, int chunk, unsigned* __restrict__ counts) {
-    __shared__ unsigned red[kBlock / 64];
-    const int i0 = blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    unsigned c = 0;
-    for (int i = i0 + threadIdx.x; i < i1; i += kBlock) c += p[i] >= cutoff ? 1u : 0u;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor((int)c, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-struct ToppPair { float prob; uint32_t index; };             // = lmrs_sampler::ProbIndex (lmrs_text.cpp)
-__global__ __launch_bounds__(kBlock) void topp_compact_kernel(const float* __restrict__ p, int n, float cutoff, int chunk, const unsigned* __restrict__ counts,
-                                                              ToppPair* __restrict__ out, unsigned* __restrict__ n0) {
-    __shared__ unsigned red[kBlock / 64], wsum[kBlock / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // candidates in the chunks before this one (gridDim.x <= kBlock counts)
-    unsigned before = (int)threadIdx.x < (int)blockIdx.x ? counts[threadIdx.x] : 0u;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) before += __shfl_xor((int)before, off);
-    if (lane == 0) red[wave] = before;
-    __syncthreads();
-    unsigned base = red[0] + red[1] + red[2] + red[3];
-    const int i0 = blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    for (int j0 = i0; j0 < i1; j0 += kBlock) {                // kBlock consecutive elements per round, one per thread: index order
-        const int i = j0 + (int)threadIdx.x;
-        const float v = i < i1 ? p[i] : 0.0f;
-        const bool keep = i < i1 && v >= cutoff;
-        const unsigned long long m = __ballot(keep);
-        const unsigned below = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        __syncthreads();                                      // (wsum of the previous round has been read)
-        if (lane == 0) wsum[wave] = (unsigned)__popcll(m);
-        __syncthreads();
-        unsigned wbase = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) wbase += wsum[w]; total += wsum[w]; }
-        if (keep) out[base + wbase + below] = ToppPair{v, (uint32_t)i};
-        base += total;
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n0 = base;
-}
-hipError_t launch_sample_topp_filter(const SampleArgs& a, float cutoff, void* pairs, unsigned* n0, unsigned* counts, hipStream_t s) {
-    if (a.n <= 0 || !a.logits || !a.part || !a.sum || !pairs || !n0 || !counts) return hipErrorInvalidValue;
+hipError_t launch_sample_exps(const SampleArgs& a, hipStream_t s) {
+    if (a.n <= 0 || !a.logits || !a.part) return hipErrorInvalidValue;
     LMRS_LAUNCH_GRID(sample_scale_max_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
     LMRS_LAUNCH_GRID(sample_exp_kernel, dim3(kSampleGrid), kBlock, 0, s, a, (int)kSampleGrid);
-    LMRS_LAUNCH_GRID(sample_sum_kernel, dim3(1), 64, 0, s, a);
-    LMRS_LAUNCH_GRID(sample_div_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
-    const int chunk = (a.n + kSampleGrid - 1) / kSampleGrid;
-    LMRS_LAUNCH_GRID(topp_count_kernel, dim3(kSampleGrid), kBlock, 0, s, (const float*)a.logits, a.n, cutoff, chunk, counts);
-    LMRS_LAUNCH_GRID(topp_compact_kernel, dim3(kSampleGrid), kBlock, 0, s, (const float*)a.logits, a.n, cutoff, chunk, (const unsigned*)counts, static_cast<ToppPair*>(pairs), n0);
-    return hipGetLastError();
-}
-
-hipError_t launch_sample_mult(const SampleArgs& a, hipStream_t s) {
-    if (a.n <= 0 || !a.logits || !a.part || !a.sum || !a.out_token) return hipErrorInvalidValue;
-    LMRS_LAUNCH_GRID(sample_scale_max_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
-    LMRS_LAUNCH_GRID(sample_exp_kernel, dim3(kSampleGrid), kBlock, 0, s, a, (int)kSampleGrid);
-    LMRS_LAUNCH_GRID(sample_sum_kernel, dim3(1), 64, 0, s, a);
-    LMRS_LAUNCH_GRID(sample_div_kernel, dim3(kSampleGrid), kBlock, 0, s, a);
-    LMRS_LAUNCH_GRID(sample_pick_kernel, dim3(1), 64, 0, s, a);
     return hipGetLastError();
 }
 

@@ -292,6 +292,31 @@ extern "C" int lmrs_sampler_topp_pairs(lmrs_sampler* s, const void* pairs, size_
     return topp_tail(s, n0, random_f32(s->seed), next);
 }
 
+// Sampler::sample from the softmax's exponentials on (functional.rs:134-139, sampler.rs:119-128), for a caller that formed
+// exps[i] = exp(logits[i] / temperature - max) elsewhere (lmrs_forward_sample: on the device, the only part of the sampler that is parallel work).
+// What is left is the reference's two sequential chains - the softmax sum and the running cdf (or the candidates' sort) - and those run
+// here: a host core adds a dependent f32 in ~1 ns, one GPU lane in ~2.5 ns.  exps become the probabilities, as `logits` does in the reference.
+extern "C" int lmrs_sampler_sample_exps(lmrs_sampler* s, float* exps, uint32_t* next) {
+    if (!s || !exps || !next) return text_fail("NULL argument");
+    if (s->temperature == 0.0f) return text_fail("temperature 0 is sample_argmax: no softmax to finish");
+    const size_t n = s->vocab_size;
+    float sum = 0.0f;
+    for (size_t i = 0; i < n; ++i) sum = sum + exps[i];                              // functional.rs:134 (the adds of the exp loop, in its order)
+    for (size_t i = 0; i < n; ++i) exps[i] = exps[i] / sum;                           // :137-139
+    const float rnd = random_f32(s->seed);
+    if (s->top_p <= 0.0f || s->top_p >= 1.0f) {                                       // sample_mult :43-55
+        float cdf = 0.0f;
+        for (size_t i = 0; i < n; ++i) { cdf = cdf + exps[i]; if (rnd < cdf) { *next = (uint32_t)i; return 0; } }
+        *next = (uint32_t)(n - 1);
+        return 0;
+    }
+    size_t n0 = 0;                                                                    // sample_topp :67-106
+    const float cutoff = (1.0f - s->top_p) / (float)(n - 1);
+    for (size_t i = 0; i < n; ++i)
+        if (exps[i] >= cutoff) { s->probindex[n0].index = (uint32_t)i; s->probindex[n0].prob = exps[i]; ++n0; }
+    return topp_tail(s, n0, rnd, next);
+}
+
 // Sampler::sample (sampler.rs:109-129).  logits (vocab_size floats) are scaled and softmax-ed IN PLACE when temperature != 0, as
 // the reference does to the slice `forward` returned.  The random number is random_f32(self.seed) on every call: the seed is
 // never advanced (:119), so one Sampler draws the same number each time - reproduced.

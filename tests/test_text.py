@@ -167,6 +167,22 @@ def test_topp_from_candidate_pairs_equals_the_whole_sampler(L):
         assert b.topp_pairs(probs[keep], keep) == want, call
 
 
+def test_sampler_from_the_exponentials_equals_the_whole_sampler(L):
+    """lmrs_sampler_sample_exps (what lmrs_forward_sample hands the host: exp(logits / temperature - max), formed on the device) against the
+    ORACLE's sampler on the logits - token and probabilities, sample_mult and top-p, one persistent sampler each over many calls."""
+    rng = np.random.default_rng(12)
+    V = 5000
+    for temperature, top_p in [(0.7, 0.9), (1.2, 1.0), (0.4, 0.0), (2.0, 0.5)]:
+        a = L.Sampler(V, temperature, top_p, 99); b = O.Sampler(V, temperature, top_p, 99)
+        for call in range(12):
+            logits = (rng.standard_normal(V) * [0.5, 8.0, 30.0][call % 3]).astype(np.float32)
+            t = (logits / np.float32(temperature)).astype(np.float32)
+            exps = np.array([O.expf(float(v)) for v in (t - t.max()).astype(np.float32)], np.float32)
+            want_p = logits.copy(); want = b.sample(want_p)
+            assert a.sample_exps(exps) == want, (temperature, top_p, call)
+            assert (exps.view(np.uint32) == want_p.view(np.uint32)).all(), "probabilities"
+
+
 def test_sampler_argmax_rule(L):
     s = L.Sampler(6, 0.0, 0.9, 1)
     assert s.sample(np.array([1, 5, 5, 2, 5, 0], np.float32)) == 1                      # first index of the maximum

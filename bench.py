@@ -126,39 +126,49 @@ def max_over_ranks(dist, seconds, device=None):
 
 
 def headline_then_guarded(headline, second, barrier, rank, limit_s, leave=os._exit):
-    """N > 1: run the headline configuration, hold its line, then run the second configuration under a watchdog on every rank; rank 0
-    prints exactly ONE JSON line whatever the second run does.  second() returning: the line carries `library_choice` with its figures.
-    second() raising on this rank, or not returning within limit_s: the line carries `library_choice: {value: null, skipped: why}` and
-    the process leaves through `leave` (os._exit: the abandoned run's collectives may never return, so no orderly teardown)."""
+    """N > 1: run the headline configuration, hold its line, then run the further configuration(s) under a watchdog on every rank; rank 0
+    prints exactly ONE JSON line whatever they do.  `second`: a callable (its figures ride along as `library_choice`) or a list of
+    (key, callable) run in order, each with its own limit_s.  A run returning: the line carries its figures under its key.  A run raising
+    on this rank, or not returning within limit_s: the line carries `<key>: {value: null, skipped: why}` (so do the runs behind it) and the
+    process leaves through `leave` (os._exit: the abandoned run's collectives may never return, so no orderly teardown)."""
     import threading
     out = headline()
     barrier()
+    extras = [("library_choice", second)] if callable(second) else list(second)
     printed = threading.Lock()
+    state = {"key": extras[0][0] if extras else None}
 
     def emit_and_leave(why):
         if not printed.acquire(blocking=False):
             return
         if rank == 0:
-            out["library_choice"] = {"value": None, "skipped": why}
+            hit = False
+            for key, _ in extras:                               # the run that failed and everything behind it
+                hit = hit or key == state["key"]
+                if hit:
+                    out[key] = {"value": None, "skipped": why if key == state["key"] else f"not run: `{state['key']}` did not finish"}
             print(json.dumps(out), flush=True)
         sys.stdout.flush(); sys.stderr.flush()
         leave(0)
 
-    dog = threading.Timer(limit_s, emit_and_leave, args=(f"the library-choice run did not finish within {limit_s:.0f} s",))
-    dog.daemon = True; dog.start()
-    try:
-        lib_out = second()
-        barrier()
-    except BaseException as e:                              # noqa: BLE001 - the headline line must get out whatever happened here
-        print(f"[rank {rank}] library-choice run failed: {type(e).__name__}: {e}", file=sys.stderr)
-        emit_and_leave(f"the library-choice run failed on a rank: {type(e).__name__}")
-        time.sleep(limit_s)                                 # (the watchdog thread is printing: wait for its exit)
-        return out
-    dog.cancel()
+    for key, run in extras:
+        state["key"] = key
+        dog = threading.Timer(limit_s, emit_and_leave, args=(f"the {key.replace('_', '-')} run did not finish within {limit_s:.0f} s",))
+        dog.daemon = True; dog.start()
+        try:
+            ex_out = run()
+            barrier()
+        except BaseException as e:                              # noqa: BLE001 - the headline line must get out whatever happened here
+            print(f"[rank {rank}] {key.replace('_', '-')} run failed: {type(e).__name__}: {e}", file=sys.stderr)
+            emit_and_leave(f"the {key.replace('_', '-')} run failed on a rank: {type(e).__name__}")
+            time.sleep(limit_s)                                 # (the watchdog thread is printing: wait for its exit)
+            return out
+        dog.cancel()
+        if rank == 0 and ex_out is not None:
+            out[key] = {k: ex_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
+            out[key]["parallelism"] = ex_out["config"]["parallelism"]
+            out[key]["roofline"] = {k: ex_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}
     if printed.acquire(blocking=False) and rank == 0:
-        out["library_choice"] = {k: lib_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
-        out["library_choice"]["parallelism"] = lib_out["config"]["parallelism"]
-        out["library_choice"]["roofline"] = {k: lib_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}
         print(json.dumps(out), flush=True)
     return out
 
@@ -526,7 +536,17 @@ def main():
             os.environ.pop("LMRS_SHARD_PLAN", None)        # (run_once(plan=...) set it for the headline run)
             return run_once(emit=False)
 
-        out = headline_then_guarded(headline, library_choice, barrier, rank, float(os.environ.get("LMRS_BENCH_LIBRARY_CHOICE_TIMEOUT", "240")))
+        def tp_split_out():
+            # SURVEY section 8(e)'s form to the letter: wo / w2 rows split dim / G as well - four gathers per layer instead of the headline's two
+            # (which keeps wo / w2 whole on every shard).  Unmeasured on hardware: the first real node answers replicate-vs-split by measurement.
+            os.environ["LMRS_SHARD_SPLIT_OUT"] = "1"
+            try:
+                return run_once(plan="tp", transport_override=None if one_dev else "rccl", emit=False)
+            finally:
+                os.environ.pop("LMRS_SHARD_SPLIT_OUT", None)
+
+        out = headline_then_guarded(headline, [("library_choice", library_choice), ("tp_split_out", tp_split_out)], barrier, rank,
+                                    float(os.environ.get("LMRS_BENCH_LIBRARY_CHOICE_TIMEOUT", "240")))
     if dist is not None:
         dist.destroy_process_group()
     return out

@@ -363,7 +363,7 @@ int enqueue_step(lmrs_ctx* c) {
 //   * tmp slices (fully row-split form) and the argmax partials: f32 / raw.
 // ------------------------------------------------------------------------------------------------
 struct ExchangeDesc { char* buf; size_t bytes, stride; const float* qsrc; size_t qn; size_t par = 0; };   // par > 0: double-buffered block, halves `par` bytes apart (exchange_push_kernel picks the half by its sequence number)   // bytes valid per shard, blocks `stride` bytes apart (in place); qsrc: f32 slice still to be quantised into this shard's block
-static bool shard_split_out() { static const bool v = getenv("LMRS_SHARD_SPLIT_OUT") != nullptr; return v; }
+static bool shard_split_out() { const char* e = getenv("LMRS_SHARD_SPLIT_OUT"); return e && atoi(e) != 0; }   // (read at every create: bench.py measures both forms in one process)
 // Which matrices to split over `world` GPUs.  Row-splitting a layer's matrices costs two exchanges per layer (four in the fully split
 // form): pure latency, a few microseconds each, every layer of every token.  It pays only when the gate / up / down stream a shard no
 // longer reads is longer than that: (w1 + w3 + w2 bytes per layer) x (1 - 1/world) at the ~6.3 TB/s a GPU streams, against ~9 us for two

@@ -1818,8 +1818,13 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
         const uint64_t etab = exp2f_tab_lane();
         const int pos = a.t.st->pos;
         const AttTag tg{a.g.gran, *a.g.seq + 1u, a.g.att_dim, a.g.kv_dim, a.err};
-        if constexpr (WAVE) attention_wave_tag<HS, GEMMA>(a.t, (int)blockIdx.x, pos, smem, etab, tg);
-        else attention_body<HS, QaGeom<HS>::NF, false, false, GEMMA, false, true>(a.t, (int)blockIdx.x, pos, smem, etab, AttPre(), tg);
+        // workgroup -> head: the query heads that share a kv head sit n_kv_heads workgroups apart - workgroup b runs on XCD b % 8, so with 8 (or 32)
+        // kv heads they share an XCD and its L2 fetches their K / V history once, not once per query head (the launch's counter traffic was 1.25 x its
+        // algorithmic bytes with head = b: profiles/r4b_traffic_llama1b_q8.json against r5_traffic_llama1b_q8.json)
+        const int nkv = a.t.n_kv_heads, bq = (int)blockIdx.x / nkv, br = (int)blockIdx.x - bq * nkv;
+        const int head = br * (nh / nkv) + bq;
+        if constexpr (WAVE) attention_wave_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
+        else attention_body<HS, QaGeom<HS>::NF, false, false, GEMMA, false, true>(a.t, head, pos, smem, etab, AttPre(), tg);
     } else {
         gemv_static_body<N, L, PRO, EPI_QKV_TAG, kBlock, Q4>(a.g, smem, (int)blockIdx.x - nh, (int)gridDim.x - nh);
     }

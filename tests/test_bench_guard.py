@@ -19,7 +19,11 @@ def second():
     if mode == "raise": raise RuntimeError("peer-to-peer handshake: no flag from a peer")
     if mode == "hang": time.sleep(60)
     return lib if rank == 0 else None
-out = bench.headline_then_guarded(lambda: head, second, lambda: None, rank, 1.0)
+def third():
+    if mode == "raise3": raise RuntimeError("split-out run failed")
+    return dict(lib, value=3000.0, config={{"parallelism": "tp2 split-out"}}) if rank == 0 else None
+runs = second if mode in ("ok", "raise", "hang") else [("library_choice", second), ("tp_split_out", third)]
+out = bench.headline_then_guarded(lambda: head, runs, lambda: None, rank, 1.0)
 print("RETURNED", flush=True)
 """
 
@@ -56,3 +60,17 @@ def test_other_ranks_print_nothing_and_leave():
     for mode in ("ok", "raise", "hang"):
         p, lines = run(mode, 1)
         assert p.returncode == 0 and not lines, (mode, p.stdout, p.stderr)
+
+
+def test_two_further_runs_both_ride_along():
+    p, lines = run("ok3", 0)
+    assert p.returncode == 0 and len(lines) == 1 and "RETURNED" in p.stdout, p.stderr
+    d = json.loads(lines[0])
+    assert d["library_choice"]["value"] == 2000.0 and d["tp_split_out"]["value"] == 3000.0 and d["tp_split_out"]["parallelism"] == "tp2 split-out"
+
+
+def test_third_run_raises_the_first_two_are_printed():
+    p, lines = run("raise3", 0)
+    assert p.returncode == 0 and len(lines) == 1 and "RETURNED" not in p.stdout, (p.stdout, p.stderr)
+    d = json.loads(lines[0])
+    assert d["value"] == 1000.0 and d["library_choice"]["value"] == 2000.0 and d["tp_split_out"]["value"] is None and "RuntimeError" in d["tp_split_out"]["skipped"]

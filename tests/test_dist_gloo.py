@@ -57,6 +57,18 @@ def _worker(rank, world, port, q):
             dist.all_gather(allr, mine_rng)
             cover = sorted((int(t[0]), int(t[1])) for t in allr)
             assert cover[0][0] == 0 and all(cover[i][0] + cover[i][1] == cover[i + 1][0] for i in range(world - 1)) and cover[-1][0] + cover[-1][1] == total
+        # the fully row-split form (wo / w2 rows split dim / G as well, four gathers per layer): dim_rows partitioned too, and a
+        # wo-shaped projection gathered from the shards' row slices is the unsharded one
+        os.environ["LMRS_SHARD_SPLIT_OUT"] = "1"
+        ps = lmrs_amd.shard_plan(a, rank, world)
+        del os.environ["LMRS_SHARD_SPLIT_OUT"]
+        assert ps["dim_rows"] == (rank * (cfg.dim // world), cfg.dim // world) and ps["q_heads"] == plan["q_heads"] and ps["hidden_pairs"] == plan["hidden_pairs"]
+        d0, dc = ps["dim_rows"]
+        wo_q = rng.integers(-127, 128, size=cfg.dim * n, dtype=np.int8); wo_s = rng.uniform(1e-4, 3e-3, size=cfg.dim * n // 128).astype(np.float32)
+        mine_o = O.matmul_q8(xq, xs, wo_q[d0 * n:(d0 + dc) * n], wo_s[d0 * n // 128:(d0 + dc) * n // 128], n, dc)
+        parts_o = [torch.zeros(dc) for _ in range(world)]
+        dist.all_gather(parts_o, torch.from_numpy(mine_o))
+        assert (torch.cat(parts_o).numpy().view(np.uint32) == O.matmul_q8(xq, xs, wo_q, wo_s, n, cfg.dim).view(np.uint32)).all()
         # q heads stay with their kv head (kv_mul q heads per kv head)
         kv_mul = cfg.n_heads // cfg.n_kv_heads
         assert plan["q_heads"][0] == plan["kv_heads"][0] * kv_mul and plan["q_heads"][1] == plan["kv_heads"][1] * kv_mul

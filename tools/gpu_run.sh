@@ -34,9 +34,12 @@ while [ $# -gt 0 ]; do
         echo "stats $N rc $?"; cp $(ls $OUT/st_$N/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/kernel_stats_$N.csv 2>/dev/null; rm -rf $OUT/st_$N;;
     pmc) M=$1; Q=$2; shift 2; N=$(short $M)_$Q
         for c in FETCH_SIZE WRITE_SIZE; do
-            rm -rf $OUT/pmc_${N}_$c
-            env ${PROF_ENV:-LMRS_NO_GRAPH=1} timeout -k 5 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${N}_$c -- python bench.py --model $M --qtype $Q --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_${N}_$c.log 2>&1
-            echo "pmc $N $c rc $?"
+            for try in 1 2 3; do                            # (rocprofv3 1.1's counter collection hangs or dies at start-up now and then, whatever the workload)
+                rm -rf $OUT/pmc_${N}_$c
+                env ${PROF_ENV:-LMRS_NO_GRAPH=1} timeout -k 5 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${N}_$c -- python bench.py --model $M --qtype $Q --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_${N}_$c.log 2>&1
+                echo "pmc $N $c try $try rc $?"
+                ls $OUT/pmc_${N}_$c/*/*counter_collection.csv > /dev/null 2>&1 && break
+            done
         done
         f=$(ls $OUT/pmc_${N}_FETCH_SIZE/*/*counter_collection.csv 2>/dev/null | head -1); w=$(ls $OUT/pmc_${N}_WRITE_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
         if [ -n "$f" ] && [ -n "$w" ]; then python tools/pmc_summary.py "$f" "$w" $OUT/traffic_$N.json $M $Q; fi

@@ -2325,6 +2325,7 @@ hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s) {
 
 #include "lmrs_prefill.inc"
 #include "lmrs_f32.inc"        // (its batched kernel uses the epilogues of lmrs_prefill.inc)
+#include "lmrs_vision_att.h"
 #include "lmrs_vision.inc"
 
 }  // namespace lmrs

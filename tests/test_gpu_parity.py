@@ -566,6 +566,25 @@ def test_gemma_2b_q4_greedy_token_ids(L):
     print(f"\ngemma-2-2b q4_0: {31/sec:.0f} tok/s")
 
 
+def test_gemma_2b_q4_batched_prefill_at_full_size(L):
+    """Gemma-2-2B Q4_0 at full size through fill_kv_cache (forward_layer over a batch, transformer.rs:672-684): 300 embeddings - the
+    packed-nibble weights through the ring kernel's 256 x 128 (gate / up), 128 x 128 and 64 x 64 tiles, the folded norm + add rows, GELU,
+    soft-capped attention with the window - the residual stream that comes back and KV rows bit-equal to the CPU path's."""
+    cfg = "gemma-2-2b"
+    img = S.build_image(cfg, S.Q4_0, seed=77)
+    toks = S.prompt_tokens(cfg, 300, 78)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    emb = m.get_embeddings(toks)
+    assert_bit_equal(emb, orc.get_embeddings(toks), "embeddings")
+    a = emb.copy(); b = emb.copy()
+    assert m.fill_kv_cache(a, 0) == 300 and orc.fill_kv_cache(b, 0) == 300
+    assert_bit_equal(a, b, "residual stream after 300 batched tokens")
+    for l in (0, m.args.n_layers - 1):
+        for which in (0, 1):
+            for pos in (0, 150, 299):
+                assert_bit_equal(m.kv_row(which, l, pos), orc.kv_row(which, l, pos), f"kv[{which}] layer {l} pos {pos}")
+
+
 @pytest.mark.parametrize("cfg,n_steps", [("mini-llama-long", 700), ("mini-phi-long", 400)])
 def test_long_context_multi_chunk_attention(L, cfg, n_steps):
     """Positions beyond one LDS chunk of K/V rows (256 timesteps at head 64, 160 at head 96): the chunked score and

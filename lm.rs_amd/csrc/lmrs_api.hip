@@ -78,6 +78,7 @@ struct lmrs_ctx {
     bool pf_ready = false;                                 // every prefill buffer above is allocated
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool no_graph = false;                         // LMRS_NO_GRAPH=1 (read at create): steps are enqueued launch by launch (profiling aid, see launch_step)
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
     bool q4 = false, f32 = false;                  // f32: q_type None (unquantised weights, lmrs_f32.inc)
     // ---- row sharding.  Every shard owns whole output rows, so every float accumulation chain
@@ -1013,6 +1014,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         if (c->qkv_att && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 1)) c->qa_wave_T = qkv_attn_wave_T((int)a.head_size);   // LMRS_QKV_ATT=1: workgroup form only
         if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = 0;                  // (its prefetch reads whole 64-row blocks of the caches)
     }
+    c->no_graph = getenv("LMRS_NO_GRAPH") != nullptr;
     if (!sharded) { const int k = getenv("LMRS_STEPS_PER_GRAPH") ? atoi(getenv("LMRS_STEPS_PER_GRAPH")) : 4; c->multi_k = k < 1 ? 1 : (k > 64 ? 64 : k); }   // (measured: 4 steps per launch +1.5 % on a 20-step run, no effect on long runs)
     c->cls_tail = !sharded && !f32w && V < (1u << 20) - 1 && !(getenv("LMRS_CLS_TAIL") && atoi(getenv("LMRS_CLS_TAIL")) == 0);
     if (!sharded) {
@@ -1092,8 +1094,7 @@ static int launch_step(lmrs_ctx* c, uint32_t pos) {
     }
     // profiling aid (LMRS_NO_GRAPH=1): the same launches enqueued one by one instead of a graph replay - rocprofv3 1.1's dispatch interceptor
     // segfaults on the graph launches of every model but Llama-3.2-1B (profiles/README.md); token ids are the same either way
-    static const bool no_graph = getenv("LMRS_NO_GRAPH") != nullptr;
-    if (no_graph && !sharded && c->g_step) {
+    if (c->no_graph && !sharded && c->g_step) {
         c->qa_mode = want_split ? 0 : qa_mode_for(c, pos); c->att_split_chunks = want_split ? 4 << b : 0; c->dbg_node = 0;
         const int rc = enqueue_step(c);
         c->qa_mode = 0; c->att_split_chunks = 0;
@@ -1410,7 +1411,7 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
         const uint32_t p = start_pos + (uint32_t)s;
         const int K = c->multi_k;
         const bool split_soon = c->att_split_pos > 0 && (int)(p + K - 1) >= c->att_split_pos;
-        if (K > 1 && c->g_step && !c->dbg && !getenv("LMRS_NO_GRAPH") && s + K <= steps && !split_soon && qa_mode_for(c, p) == qa_mode_for(c, p + K - 1)) {
+        if (K > 1 && c->g_step && !c->dbg && !c->no_graph && s + K <= steps && !split_soon && qa_mode_for(c, p) == qa_mode_for(c, p + K - 1)) {
             const int mode = qa_mode_for(c, p);
             if (!c->g_multi[mode]) {
                 c->qa_mode = mode;

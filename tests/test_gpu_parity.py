@@ -898,6 +898,19 @@ def test_merged_qkv_attention_launch_and_classifier_tail(L, monkeypatch, cfg, q)
         assert m.forward_argmax(int(toks[pos]), pos) == int(toks[pos + 1]) or pos < len(prompt) - 1
 
 
+def test_steps_enqueued_without_a_graph_give_the_same_tokens(L, monkeypatch):
+    """LMRS_NO_GRAPH=1 (the profiling aid: rocprofv3 1.1 dies on the graph launches of most models) enqueues a step's launches one by one -
+    same kernels, same order: token ids and logits as the CPU path's, across the wave -> workgroup switch of the merged launch."""
+    img = S.build_image("mini-llama", S.Q8_0, seed=43)
+    prompt = S.prompt_tokens("mini-llama", 6, 43)
+    orc = O.Oracle(img)
+    ref = orc.generate_greedy(prompt, 140)
+    monkeypatch.setenv("LMRS_NO_GRAPH", "1")
+    m = L.Transformer(img)
+    assert (m.generate_greedy(prompt, 140) == ref).all()
+    assert_bit_equal(m.forward(int(ref[-1]), 6 + 139), orc.forward(int(ref[-1]), 6 + 139), "logits, eager step")
+
+
 def test_classifier_tags_survive_2047_layers_only_steps(L, monkeypatch):
     """The folded argmax tags its packed partials with 11 bits of a counter.  That counter used to be the step counter, which the
     layers-only steps of a token-by-token fill bump as well: exactly 2047 of them between two decode steps made the previous step's

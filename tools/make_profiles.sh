@@ -5,7 +5,7 @@
 #   usage: bash tools/make_profiles.sh <tag> [pmc|lite|extra]   (e.g. r4; `pmc`: only the counter passes and the bench lines that quote them;
 #          `lite`: counters, rocprofv3 kernel statistics and the bench lines of the four models - no timeline / prefill / vision / two-rank runs)
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 export LMRS_BENCH_IMAGE_CACHE=/tmp          # the synthetic images are built once, outside the profiler
@@ -19,8 +19,8 @@ pmc() {   # model qtype out-json
         for try in 1 2 3; do
             rm -rf $OUT/pmc_$1_$c
             KT=--kernel-trace; [ $try = 3 ] && KT=            # (last try: counters alone - the trace + counter combination is what crashed on Gemma-2-2B in round 3)
-            AQLENV=; [ "$1" != llama-3.2-1b ] && AQLENV="LMRS_AQL=1 LMRS_AQL_HOST_KERNARG=1"      # (see stats(): the graph path of the larger models crashes the profiler)
-            env $AQLENV LMRS_STEPS_PER_GRAPH=1 timeout -k 5 90 rocprofv3 $KT --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
+            # (LMRS_NO_GRAPH=1: the step's launches enqueued one by one - rocprofv3 1.1 segfaults on the graph launches of every model but Llama-3.2-1B)
+            env LMRS_NO_GRAPH=1 timeout -k 5 90 rocprofv3 $KT --pmc $c --output-format csv -d $OUT/pmc_$1_$c -- python bench.py --model $1 --qtype $2 --steps 16 --warmup 4 --cpu-steps 0 > $OUT/pmc_$1_$c.log 2>&1
             ls $OUT/pmc_$1_$c/*/*counter_collection.csv > /dev/null 2>&1 && break
         done
     done
@@ -34,18 +34,15 @@ stats() {   # model qtype short-name: their bench line (which also leaves the im
     timeout 400 python bench.py --model $1 --qtype $2 --steps 64 > $OUT/${TAG}_bench_$3.json 2>> $OUT/bench.err
     for try in 1 2 3; do                                # (rocprofv3 1.1 segfaults at start-up now and then, whatever the workload)
         rm -rf $OUT/st_$3
-        # (through the AQL launch path with host-resident argument blocks: rocprofv3 1.1's interceptor copies every dispatch's argument block on the
-        # host and segfaults - for these three models every time - on the device-resident blocks of HIP graphs; same kernels, same order)
-        LMRS_AQL=1 LMRS_AQL_HOST_KERNARG=1 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$3 -- python bench.py --model $1 --qtype $2 --steps 64 --cpu-steps 0 > $OUT/st_$3.log 2>&1
+        # (LMRS_NO_GRAPH=1: the same launches enqueued one by one - rocprofv3 1.1 segfaults inside hipGraphLaunch for these three models, every time,
+        # with or without kernel-argument preload, one or four steps per graph: profiles/README.md; same kernels, same order)
+        LMRS_NO_GRAPH=1 timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$3 -- python bench.py --model $1 --qtype $2 --steps 64 --cpu-steps 0 > $OUT/st_$3.log 2>&1
         ls $OUT/st_$3/*/*kernel_stats.csv > /dev/null 2>&1 && break
     done
     cp $(ls $OUT/st_$3/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats_$3.csv 2>/dev/null; rm -rf $OUT/st_$3
 }
-if [ "$ONLY" != extra ]; then pmc llama-3.2-1b q8_0 $OUT/${TAG}_traffic_llama1b_q8.json; fi
-if [ "$ONLY" = extra ]; then stats gemma-2-2b q4_0 gemma2b_q4; pmc gemma-2-2b q4_0 $OUT/${TAG}_traffic_gemma2b_q4.json; stats llama-3.2-3b q8_0 llama3b; stats phi-3.5 q8_0 phi35; exit 0; fi
-# (Gemma-2-2B, Llama-3.2-3B, Phi-3.5: rocprofv3 1.1 segfaults inside its dispatch interceptor on the first decode step of these models, every
-# time, through hipGraph replays and through hand-written AQL packets alike - profiles/r4_rocprofv3_crash_*.log.  `extra` retries them; the
-# default run records their bench lines, whose roofline.in_step carries the HIP-event duration of every launch inside the real step.)
+if [ "$ONLY" != extra ]; then pmc llama-3.2-1b q8_0 $OUT/${TAG}_traffic_llama1b_q8.json; pmc gemma-2-2b q4_0 $OUT/${TAG}_traffic_gemma2b_q4.json; fi
+if [ "$ONLY" = extra ]; then stats gemma-2-2b q4_0 gemma2b_q4; stats llama-3.2-3b q8_0 llama3b; stats phi-3.5 q8_0 phi35; exit 0; fi
 if [ "$ONLY" = pmc ]; then timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2>> $OUT/bench.err; exit 0; fi
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --cpu-steps 0 > $OUT/stats.log 2>&1
@@ -53,13 +50,15 @@ cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv; 
 python tools/rocprof_summary.py $OUT/${TAG}_kernel_stats.csv $OUT/${TAG}_rocprof_llama1b_q8.json llama-3.2-1b q8_0 && cp $OUT/${TAG}_rocprof_llama1b_q8.json profiles/   # bench.py reads it (frac_rocprof)
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err                      # again: now with frac_rocprof and traffic of this build
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2>> $OUT/bench.err   # the driver's invocation
-timeout 300 python bench.py --model gemma-2-2b --qtype q4_0 --steps 64 > $OUT/${TAG}_bench_gemma2b_q4.json 2>> $OUT/bench.err
-timeout 400 python bench.py --model llama-3.2-3b --steps 64 > $OUT/${TAG}_bench_llama3b.json 2>> $OUT/bench.err
-timeout 400 python bench.py --model phi-3.5 --steps 64 > $OUT/${TAG}_bench_phi35.json 2>> $OUT/bench.err
+stats gemma-2-2b q4_0 gemma2b_q4; stats llama-3.2-3b q8_0 llama3b; stats phi-3.5 q8_0 phi35        # (each also rewrites its bench line)
 if [ "$ONLY" = lite ]; then exit 0; fi          # (`lite`: counters, kernel statistics and the bench lines of the four models only)
 timeout 200 python tools/timeline.py llama-3.2-1b 100 > $OUT/${TAG}_timeline_llama1b.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf -- python tools/prefill_rate.py llama-3.2-1b 512 > $OUT/${TAG}_prefill512.log 2>&1
 cp $(ls $OUT/pf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prefill512_kernel_stats.csv; rm -rf $OUT/pf
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf -- python tools/prefill_rate.py llama-3.2-1b 256 > $OUT/${TAG}_prefill256.log 2>&1
+cp $(ls $OUT/pf/*/*kernel_stats.csv | head -1) $OUT/${TAG}_prefill256_kernel_stats.csv; rm -rf $OUT/pf
+{ python tools/prefill_rate.py gemma-2-2b 256 q4_0; python tools/prefill_rate.py llama-3.2-3b 512; python tools/prefill_rate.py phi-3.5 320; } 2>&1 | grep fill_kv > $OUT/${TAG}_prefill_other_models.txt
+timeout 300 python tools/sampler_rate.py > $OUT/${TAG}_sampler_rate.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vis -- python tools/vision_rate.py 2 24 > $OUT/${TAG}_vision_rate.log 2>&1
 cp $(ls $OUT/vis/*/*kernel_stats.csv | head -1) $OUT/${TAG}_vision_kernel_stats.csv; rm -rf $OUT/vis
 LMRS_BENCH_ONE_DEVICE=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29581 bench.py --gpus 2 --steps 64 --warmup 16 --cpu-steps 8 2> $OUT/tp2.err | grep "^{" > $OUT/${TAG}_bench_two_ranks_one_device_both_plans.json

@@ -606,14 +606,15 @@ int queue_err(lmrs_ctx* c) {
     return 0;
 }
 int check_err(lmrs_ctx* c) {
+    const bool queued = c->err_queued;                           // (cleared on EVERY path out of here: a stale flag would make a later call skip the copy)
+    c->err_queued = false;
     if (c->xerr) {
         int e = 0;
         HIP_OK(hipMemcpy(&e, c->xerr, 4, hipMemcpyDeviceToHost));
         if (e) { (void)hipMemset(c->xerr, 0, 4); return fail("peer-to-peer exchange " + std::to_string(e - 1) + " timed out waiting for a peer (results of this call are invalid)"); }
     }
     if (!c->err || !(c->qkv_att || c->cls_tail)) return 0;
-    if (c->err_queued) c->err_queued = false;                   // already copied by the stream, ahead of the synchronise the caller just did
-    else HIP_OK(hipMemcpy(c->h_err, c->err, 4, hipMemcpyDeviceToHost));
+    if (!queued) HIP_OK(hipMemcpy(c->h_err, c->err, 4, hipMemcpyDeviceToHost));   // (queued: already copied by the stream, ahead of the synchronise the caller just did)
     if (*c->h_err) return fail("in-launch synchronisation timed out at stage " + std::to_string(*c->h_err - 1) + " (results of this call are invalid)");
     return 0;
 }

@@ -873,9 +873,11 @@ __device__ __forceinline__ GemvArgs with_hot(const GemvArgs& a0, const float* xi
 // VGPRs: 148 under the max-ilp scheduling strategy left the 384 workgroups of the 3072-wide models one per CU, in two rounds.  Same-box A/B
 // (profiles/r5_ab_w2_launch_bounds.txt): Llama-3.2-3B 975 -> 985 tok/s, Phi-3.5 860 -> 870, Llama-3.2-1B unchanged; a grid capped at 256 / 192
 // workgroups with a second pass instead: 981 / 978.
-#define LMRS_STATIC_BOUNDS(NTH_) __launch_bounds__(NTH_, (NTH_) == 512 ? 4 : 1)
+// Not for Gemma-2-2B's 9216-wide class: under the bound it spills (20 / 24 bytes of scratch per lane) and its w2 launch went 5.3 -> 7.5 us
+// (profiles/r5_bench_gemma2b_q4.json of the first r5 artefact run against r4b: 1139 -> 1088 tok/s); its 36-72 workgroups never share a CU anyway.
+#define LMRS_STATIC_BOUNDS(N_, NTH_) __launch_bounds__(NTH_, ((NTH_) == 512 && (N_) <= 8192) ? 4 : 1)
 template <int N, int L, int PRO, int EPI, int NTH, bool Q4 = false>
-__global__ LMRS_STATIC_BOUNDS(NTH) void gemv_static_kernel(LMRS_HOT_PARAMS, const GemvArgs a0) {
+__global__ LMRS_STATIC_BOUNDS(N, NTH) void gemv_static_kernel(LMRS_HOT_PARAMS, const GemvArgs a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemvArgs a = with_hot(a0, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out);
     gemv_static_body<N, L, PRO, EPI, NTH, Q4>(a, smem, (int)blockIdx.x, (int)gridDim.x);

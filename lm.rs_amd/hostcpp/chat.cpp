@@ -92,8 +92,7 @@ int main(int argc, char** argv) {
             }
             const auto t0 = std::chrono::steady_clock::now();
             if (temperature == 0.0f) next = model.forward_argmax(token, pos);                     // :214-215, argmax fused on the device
-            else if (top_p > 0.0f && top_p < 1.0f) next = sampler.forward_sample(model, token, pos);   // :124-126 sample_topp (the default flags, :28-31): scaling, softmax and the cutoff filter on the device, only the candidates cross to the host
-            else next = sampler.sample(model.forward(token, pos));                                // sample_mult: on the host (the device form draws the same token but its two 128 256-term chains are slower than the 513 KB copy - DESIGN.md section 9)
+            else next = sampler.forward_sample(model, token, pos);   // :115-128: scaling, maximum and exponentials on the device, the two sequential chains and sample_mult / sample_topp on the host
             pos += 1;
             if (user_idx >= num_prompt_tokens && next != tokenizer.eos && !(mt == ModelType::GEMMA && next == 107)) {   // :218-222
                 std::fputs(tokenizer.decode(next).c_str(), stdout); std::fflush(stdout);

@@ -2,7 +2,9 @@
 # Regenerates the round's measurement artefacts on a GPU box (run from the repo root through gpurun); everything lands in
 # gpurun_out/art/ and is copied into profiles/ by hand afterwards.  PMC counters are collected in their own rocprofv3 runs
 # (--kernel-trace only, one counter per pass), as /opt/skills/guides/MI355X_MICROARCH.md prescribes.
-#   usage: bash tools/make_profiles.sh <tag> [pmc|lite|extra]   (e.g. r4; `pmc`: only the counter passes and the bench lines that quote them;
+#   usage: bash tools/make_profiles.sh <tag> [pmc|lite|extra|hash]   (`hash`: only what bench.py matches by the build identifier - the Llama-3.2-1B and Gemma
+#          traffic summaries, the rocprofv3 summary - and the two Llama-3.2-1B bench lines that quote them)
+#   modes: [pmc|lite|extra]   (e.g. r4; `pmc`: only the counter passes and the bench lines that quote them;
 #          `lite`: counters, rocprofv3 kernel statistics and the bench lines of the four models - no timeline / prefill / vision / two-rank runs)
 set -u
 TAG=${1:-r5}
@@ -11,6 +13,7 @@ cd "$GRAFT_REPO_ROOT"
 export LMRS_BENCH_IMAGE_CACHE=/tmp          # the synthetic images are built once, outside the profiler
 OUT=gpurun_out/art; ONLY=${2:-all}
 if [ "$ONLY" = all ] || [ "$ONLY" = lite ]; then rm -rf $OUT; fi
+if [ "$ONLY" = hash ]; then HASHONLY=1; ONLY=lite; fi
 mkdir -p $OUT
 pmc() {   # model qtype out-json
     for c in FETCH_SIZE WRITE_SIZE; do
@@ -50,6 +53,7 @@ cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv; 
 python tools/rocprof_summary.py $OUT/${TAG}_kernel_stats.csv $OUT/${TAG}_rocprof_llama1b_q8.json llama-3.2-1b q8_0 && cp $OUT/${TAG}_rocprof_llama1b_q8.json profiles/   # bench.py reads it (frac_rocprof)
 timeout 300 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err                      # again: now with frac_rocprof and traffic of this build
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_20steps.json 2>> $OUT/bench.err   # the driver's invocation
+if [ "${HASHONLY:-0}" = 1 ]; then exit 0; fi
 stats gemma-2-2b q4_0 gemma2b_q4; stats llama-3.2-3b q8_0 llama3b; stats phi-3.5 q8_0 phi35        # (each also rewrites its bench line)
 if [ "$ONLY" = lite ]; then exit 0; fi          # (`lite`: counters, kernel statistics and the bench lines of the four models only)
 timeout 200 python tools/timeline.py llama-3.2-1b 100 > $OUT/${TAG}_timeline_llama1b.txt 2>&1

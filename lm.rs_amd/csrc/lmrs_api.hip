@@ -76,6 +76,9 @@ struct lmrs_ctx {
     // batched forward_layer (fill_kv_cache): device buffers for kPrefillTokens tokens, allocated on first use
     float *pf_x = nullptr, *pf_q = nullptr, *pf_k = nullptr, *pf_ao = nullptr, *pf_h = nullptr, *pf_xs = nullptr, *pf_t = nullptr; int8_t* pf_xq = nullptr; float* pf_att = nullptr; size_t pf_att_cap = 0;
     bool pf_ready = false;                                 // every prefill buffer above is allocated
+    // batched prefill on row shards (plan "tp", Q8_0): the gathered blocks of a token batch - per shard [n_tok x slice int8 | n_tok x slice / 128 scales],
+    // pfb_att / pfb_h bytes apart; inside the peer-to-peer arena when that is the transport (peers write them), ordinary memory for RCCL
+    char *pfx_att = nullptr, *pfx_h = nullptr; size_t pfb_att = 0, pfb_h = 0; bool pfx_owned = false;
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool no_graph = false;                         // LMRS_NO_GRAPH=1 (read at create): steps are enqueued launch by launch (profiling aid, see launch_step)
@@ -127,6 +130,19 @@ __global__ void advance_pos_kernel(DevState* st, unsigned* seq) { st->pos += 1; 
 __global__ void stall_kernel(long long ticks) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32); }   // lmrs_debug_inject
 
 size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+constexpr int kPrefillTokens = 512;            // tokens per pass of the batched forward_layer (fill_kv_cache, the prompt of generate_greedy)
+// Batched prefill on ROW SHARDS (plan "tp"): the configurations it is built for - Q8_0 with whole 128-groups per shard (the quantised
+// exchange payload of the decode step), wo / w2 replicated, Llama / Phi head sizes; everything else feeds its tokens one by one.
+bool prefill_tp_shapes_ok(const lmrs_ctx* c) {
+    const lmrs_args& a = c->args;
+    if (!c->qpay || !c->rep_out || c->cls_only || a.model_type == LMRS_GEMMA || getenv("LMRS_NO_BATCHED_PREFILL")) return false;
+    if (!rows_prologue_supported((int)a.dim)) return false;
+    if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
+    return (c->att_dim + 2 * c->kv_dim) % 16 == 0 && c->kv_dim % 4 == 0 && a.dim % 16 == 0 && c->att_full % 128 == 0 && a.hidden_dim % 128 == 0;
+}
+// bytes of one shard's block for a slice of n_l values per token: [kPrefillTokens x n_l int8 | kPrefillTokens x n_l / 128 f32]
+size_t prefill_tp_block(size_t n_l) { return pad256((size_t)kPrefillTokens * n_l + (size_t)kPrefillTokens * (n_l / 128) * 4); }
 
 // how a step at position `pos` runs qkv + attention (lmrs_ctx::qa_mode)
 int qa_mode_for(const lmrs_ctx* c, uint32_t pos) {
@@ -363,7 +379,7 @@ int enqueue_step(lmrs_ctx* c) {
 //     their workgroups re-quantising it.  Q4_0 models and LMRS_SHARD_F32_PAYLOAD=1: f32 slices.
 //   * tmp slices (fully row-split form) and the argmax partials: f32 / raw.
 // ------------------------------------------------------------------------------------------------
-struct ExchangeDesc { char* buf; size_t bytes, stride; const float* qsrc; size_t qn; size_t par = 0; };   // par > 0: double-buffered block, halves `par` bytes apart (exchange_push_kernel picks the half by its sequence number)   // bytes valid per shard, blocks `stride` bytes apart (in place); qsrc: f32 slice still to be quantised into this shard's block
+struct ExchangeDesc { char* buf; size_t bytes, stride; const float* qsrc; size_t qn; size_t par = 0; bool wide = false; };   // wide: a token batch's block (copied by many workgroups)   // par > 0: double-buffered block, halves `par` bytes apart (exchange_push_kernel picks the half by its sequence number)   // bytes valid per shard, blocks `stride` bytes apart (in place); qsrc: f32 slice still to be quantised into this shard's block
 static bool shard_split_out() { const char* e = getenv("LMRS_SHARD_SPLIT_OUT"); return e && atoi(e) != 0; }   // (read at every create: bench.py measures both forms in one process)
 // Which matrices to split over `world` GPUs.  Row-splitting a layer's matrices costs two exchanges per layer (four in the fully split
 // form): pure latency, a few microseconds each, every layer of every token.  It pays only when the gate / up / down stream a shard no
@@ -546,7 +562,7 @@ int enqueue_exchange(lmrs_ctx* c, const ExchangeDesc& e) {
         x.par_bytes = (int)e.par;
         if (e.qsrc) { x.qsrc = e.qsrc; x.qn = (int)e.qn; }      // the slice is quantised by the exchange kernel itself on its way out
         set_launch_tag(8);
-        HIP_OK(launch_exchange_push(x, c->stream));
+        HIP_OK(e.wide ? launch_exchange_copy_push(x, c->stream) : launch_exchange_push(x, c->stream));
         return 0;
     }
     if (!c->comm) return fail("this context is a member of a lock-step shard group: drive it with lmrs_group_forward");
@@ -949,12 +965,16 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         auto xneed = [&](size_t b) { const size_t o = xo; xo += pad256(b); return o; };
         const size_t o_att = xneed(att * 4), o_h = xneed(hid * 4), o_tmp = xneed(dim * 4), o_logits = xneed(V * 4), o_part = xneed(2 * W * 2 * kMaxArgmaxParts * 4),
                      o_gqa = xneed(W * c->blk_att), o_gqh = xneed(W * c->blk_h), o_flags = xneed((size_t)kMaxExchangeSlots * kMaxWorld * 4), o_seq = xneed((size_t)kMaxExchangeSlots * 4), o_err = xneed(256);
+        const bool tpb = prefill_tp_shapes_ok(c);             // token-batch blocks of the batched prefill (two buffers: see prefill_layers_tp)
+        c->pfb_att = prefill_tp_block(att_l); c->pfb_h = prefill_tp_block(hid_l);
+        const size_t o_pfa = tpb ? xneed(W * c->pfb_att) : 0, o_pfh = tpb ? xneed(W * c->pfb_h) : 0;
         HCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->xarena), xo, hipDeviceMallocFinegrained));
         c->xarena_bytes = xo;
         HCK(hipMemset(c->xarena, 0, xo));
         c->att_out = reinterpret_cast<float*>(c->xarena + o_att); c->h = reinterpret_cast<float*>(c->xarena + o_h); c->tmp = reinterpret_cast<float*>(c->xarena + o_tmp);
         c->logits = reinterpret_cast<float*>(c->xarena + o_logits); c->part = reinterpret_cast<float*>(c->xarena + o_part);
         c->gq_att = c->xarena + o_gqa; c->gq_h = c->xarena + o_gqh;
+        if (tpb) { c->pfx_att = c->xarena + o_pfa; c->pfx_h = c->xarena + o_pfh; }
         c->xflags = reinterpret_cast<unsigned*>(c->xarena + o_flags); c->xseq = reinterpret_cast<unsigned*>(c->xarena + o_seq); c->xerr = reinterpret_cast<int*>(c->xarena + o_err);
         c->peer_base[rank] = c->xarena;
         if (cls_only) {   // no peer ever writes the layers' activations: they belong in ordinary (L2-cached) memory; only the partials and logits are exchanged
@@ -1066,6 +1086,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : c->g_multi) if (g) (void)hipGraphExecDestroy(g);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
+    if (c->pfx_owned) { if (c->pfx_att) (void)hipFree(c->pfx_att); if (c->pfx_h) (void)hipFree(c->pfx_h); }
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) (void)hipHostFree(c->h_logits);
     if (c->h_tok) (void)hipHostFree(c->h_tok);
@@ -1220,7 +1241,6 @@ extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, s
 }
 
 // ------------------------------------------------------------------ batched forward_layer on the matrix cores
-constexpr int kPrefillTokens = 512;
 
 // The model shapes the static per-token prologues exist for (Llama-3.2-1B/3B, Phi-3.5, Gemma-2-2B; Q8_0 and Q4_0) on one GPU;
 // everything else takes the token-by-token path below (same results).
@@ -1239,17 +1259,20 @@ static bool prefill_batched_ok(const lmrs_ctx* c) {
 static int prefill_alloc(lmrs_ctx* c) {
     if (c->pf_ready) return 0;
     const lmrs_args& a = c->args;
-    const size_t B = kPrefillTokens, wide = std::max<size_t>(std::max<size_t>(a.dim, a.hidden_dim), (size_t)c->att_dim);
+    const size_t B = kPrefillTokens, wide = std::max<size_t>(std::max<size_t>(a.dim, a.hidden_dim), (size_t)std::max(c->att_dim, c->att_full));
+    const bool own_blocks = c->world > 1 && !c->cls_only && !c->pfx_att;        // (peer-to-peer shards: the blocks are part of the exchange arena)
+    if (own_blocks) { c->pfb_att = prefill_tp_block((size_t)c->att_dim); c->pfb_h = prefill_tp_block((size_t)c->hid_l); c->pfx_owned = true; }
     struct Want { void** p; size_t bytes; } want[] = {
         {reinterpret_cast<void**>(&c->pf_x), B * a.dim * 4}, {reinterpret_cast<void**>(&c->pf_q), B * c->att_dim * 4},
         {reinterpret_cast<void**>(&c->pf_k), B * c->kv_dim * 4}, {reinterpret_cast<void**>(&c->pf_ao), B * c->att_dim * 4},
         {reinterpret_cast<void**>(&c->pf_h), B * a.hidden_dim * 4}, {reinterpret_cast<void**>(&c->pf_xq), B * wide},
-        {reinterpret_cast<void**>(&c->pf_xs), B * (wide / 128) * 4}, {reinterpret_cast<void**>(&c->pf_t), a.model_type == LMRS_GEMMA ? B * a.dim * 4 : 0}};
+        {reinterpret_cast<void**>(&c->pf_xs), B * (wide / 128) * 4}, {reinterpret_cast<void**>(&c->pf_t), a.model_type == LMRS_GEMMA ? B * a.dim * 4 : 0},
+        {reinterpret_cast<void**>(&c->pfx_att), own_blocks ? c->world * c->pfb_att : 0}, {reinterpret_cast<void**>(&c->pfx_h), own_blocks ? c->world * c->pfb_h : 0}};
     for (const Want& w : want) {
         if (!w.bytes || *w.p) continue;
         const hipError_t e = hipMalloc(w.p, w.bytes);
         if (e != hipSuccess) {                       // all or nothing: a half-allocated set must never reach the kernels
-            for (const Want& u : want) if (*u.p) { (void)hipFree(*u.p); *u.p = nullptr; }
+            for (const Want& u : want) if (u.bytes && *u.p) { (void)hipFree(*u.p); *u.p = nullptr; }      // (bytes == 0: not ours to free - Gemma's pf_t absent, blocks inside the exchange arena)
             return fail(std::string("prefill buffers: hipMalloc: ") + hipGetErrorString(e));
         }
     }
@@ -1312,11 +1335,75 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
     return 0;
 }
 
+// The same on ROW SHARDS (plan "tp"; prefill_tp_shapes_ok): every shard runs the GEMMs of its own rows over the token batch - its heads' q / k / v
+// rows and attention, its gate / up pairs - and wo / w2 whole (replicated rows), so two exchanges per layer, as in the decode step: each shard
+// quantises ITS slice of every token's att_out / h (whole 128-groups: bit for bit the groups of the gathered vector), the blocks are
+// all-gathered (RCCL, or the push transport's wide copy) and laid out as the next GEMM's activation operand.  The att and h blocks are TWO
+// buffers: a peer can only write block A of layer l + 1 after it has seen this shard's flag of exchange H of layer l, which this shard
+// raises after it has consumed A of layer l (stream order) - and the other way round.
+static int prefill_layers_tp(lmrs_ctx* c, int m, int p0) {
+    const lmrs_args& a = c->args;
+    const int dim = (int)a.dim, hid = (int)a.hidden_dim, att = c->att_dim, kv = c->kv_dim, hs = (int)a.head_size, W = c->world;
+    const float eps = a.rms_norm_eps;
+    auto all_gather = [&](const float* mine, int n_l, char* blocks, size_t cap) -> int {          // mine: [m][n_l] f32 -> pf_xq / pf_xs [m][W * n_l]
+        const size_t s_off = (size_t)m * n_l, bytes = s_off + (size_t)m * (n_l / 128) * 4, stride = pad256(bytes);
+        if (stride > cap) return fail("prefill block overflow");
+        char* blk = blocks + (size_t)c->rank * stride;
+        HIP_OK(launch_quantize_rows(mine, n_l, m, reinterpret_cast<int8_t*>(blk), reinterpret_cast<float*>(blk + s_off), c->stream));
+        ExchangeDesc e{blocks, bytes, stride, nullptr, 0}; e.wide = true;
+        if (enqueue_exchange(c, e)) return -1;
+        HIP_OK(launch_gather_rows(blocks, stride, s_off, W, n_l, m, c->pf_xq, c->pf_xs, c->stream));
+        return 0;
+    };
+    for (uint32_t l = 0; l < a.n_layers; ++l) {
+        const DevLayer& L = c->layers[l];
+        GemmArgs g{};
+        g.xq = c->pf_xq; g.xs = c->pf_xs; g.n_tok = m; g.q4 = 0;
+        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, nullptr, nullptr, eps, 0, 1, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
+        g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
+        HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
+        HIP_OK(launch_rope_rows(c->pf_q, c->pf_k, c->k_cache, c->rope, att / hs, kv / hs, hs, (int)a.seq_len, (int)l, p0, m, c->stream));
+        AttnArgs t{};
+        t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
+        t.n_heads = att / hs; t.n_kv_heads = kv / hs; t.head_size = hs; t.seq_len = (int)a.seq_len; t.layer = (int)l; t.gemma = false; t.st = c->st;
+        bool blocked = false;
+        if (attention_block_supported(t, m)) {
+            const size_t need = attention_block_scratch_floats(t.n_heads, m, p0 + m);
+            if (need <= ((size_t)1 << 28)) {
+                if (need > c->pf_att_cap) {
+                    if (c->pf_att) { HIP_OK(hipStreamSynchronize(c->stream)); (void)hipFree(c->pf_att); c->pf_att = nullptr; c->pf_att_cap = 0; }
+                    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_att), need * 4)); c->pf_att_cap = need;
+                }
+                HIP_OK(launch_attention_block(t, p0, m, c->pf_att, c->stream));
+                blocked = true;
+            }
+        }
+        if (!blocked) HIP_OK(launch_attention_rows(t, p0, m, c->stream));
+        if (all_gather(c->pf_ao, att, c->pfx_att, c->pfb_att)) return -1;
+        g.wq = L.wo; g.ws = L.so; g.n = c->att_full; g.o = dim; g.out = c->pf_x;
+        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
+        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, nullptr, nullptr, eps, 0, 1, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * c->hid_l; g.out = c->pf_h;
+        HIP_OK(launch_gemm_q8(g, EPI_SWIGLU, c->stream));
+        if (all_gather(c->pf_h, c->hid_l, c->pfx_h, c->pfb_h)) return -1;
+        g.wq = L.w2; g.ws = L.s2; g.n = hid; g.o = dim; g.out = c->pf_x;
+        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
+    }
+    return 0;
+}
+static bool prefill_tp_ok(const lmrs_ctx* c) { return c->world > 1 && (c->comm || (c->p2p && c->p2p_ready)) && prefill_tp_shapes_ok(c); }
+static int prefill_pass(lmrs_ctx* c, int m, int p0) {
+    if (c->world > 1 && !c->cls_only) { c->ex_slot = 0; return prefill_layers_tp(c, m, p0); }
+    return prefill_layers(c, m, p0);
+}
+
 extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, uint32_t curr_pos, uint32_t* new_pos) {
     if (!c || !embeddings) return fail("NULL argument");
     if ((size_t)curr_pos + n > c->args.seq_len) return fail("positions out of range");
     HIP_OK(hipSetDevice(c->device));
-    if (!c->g_layers && !(c->cls_only && n > 1 && prefill_batched_ok(c))) {
+    const bool tp_batched = n > 1 && prefill_tp_ok(c);
+    if (!c->g_layers && !tp_batched && !(c->cls_only && n > 1 && prefill_batched_ok(c))) {
         // Row-sharded context: forward_layer(sl = n) is, value for value, n single-token passes through the layers; each token goes
         // through the sharded layer segments (exchanges included), every shard ends with the whole residual stream in x.
         if (!(c->comm || (c->p2p && c->p2p_ready))) return fail("fill_kv_cache: this sharded context has no transport (lock-step groups are driven by lmrs_group_forward)");
@@ -1343,7 +1430,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
         if (new_pos) *new_pos = curr_pos + n;
         return 0;
     }
-    if (prefill_batched_ok(c) && n > 1) {
+    if ((tp_batched || prefill_batched_ok(c)) && n > 1) {
         // forward_layer(sl = n): GEMMs over the token batch on the int8 matrix cores, kPrefillTokens tokens at a time
         // (a later chunk only needs the K/V rows of the earlier ones, exactly as inside the reference's single call).
         if (prefill_alloc(c)) return -1;
@@ -1353,7 +1440,7 @@ extern "C" int lmrs_fill_kv_cache(lmrs_ctx* c, float* embeddings, uint32_t n, ui
             const int m = (int)std::min<uint32_t>(kPrefillTokens, n - i0);
             HIP_OK(hipMemcpyAsync(c->pf_x, embeddings + (size_t)i0 * dim, (size_t)m * dim * 4, hipMemcpyHostToDevice, c->stream));
             if (i0 == 0) HIP_OK(hipEventRecord(c->ev0, c->stream));                     // (measurement: the layers without the first upload / the last download)
-            if (prefill_layers(c, m, (int)(curr_pos + i0))) return -1;
+            if (prefill_pass(c, m, (int)(curr_pos + i0))) return -1;
             if (i0 + kPrefillTokens >= n) HIP_OK(hipEventRecord(c->ev1, c->stream));
             HIP_OK(hipMemcpyAsync(embeddings + (size_t)i0 * dim, c->pf_x, (size_t)m * dim * 4, hipMemcpyDeviceToHost, c->stream));
         }
@@ -1396,13 +1483,13 @@ extern "C" int lmrs_generate_greedy(lmrs_ctx* c, const uint32_t* prompt, size_t 
     // prompt tokens except the last only have to leave their K/V rows behind, which is forward_layer over a batch - the
     // matrix-core path of fill_kv_cache, value for value what the per-token passes produce.
     size_t done = 0;
-    if (n_prompt >= 9 && prefill_batched_ok(c) && c->args.model_type != LMRS_GEMMA) {      // (Gemma scales its embeddings in the embed kernel)
+    if (n_prompt >= 9 && (prefill_batched_ok(c) || prefill_tp_ok(c)) && c->args.model_type != LMRS_GEMMA) {      // (Gemma scales its embeddings in the embed kernel)
         if (prefill_alloc(c)) return -1;
         const size_t m_total = n_prompt - 1;
         for (size_t i0 = 0; i0 < m_total; i0 += kPrefillTokens) {
             const int m = (int)std::min<size_t>(kPrefillTokens, m_total - i0);
             HIP_OK(launch_dequant_rows(c->emb_q, c->emb_s, c->q4, c->tokens + start_pos + i0, m, (int)c->args.dim, c->pf_x, c->stream));
-            if (prefill_layers(c, m, (int)(start_pos + i0))) return -1;
+            if (prefill_pass(c, m, (int)(start_pos + i0))) return -1;
         }
         done = m_total;
     }

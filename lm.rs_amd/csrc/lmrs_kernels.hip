@@ -2128,6 +2128,43 @@ __global__ __launch_bounds__(kBlock) void quantize_kernel(const float* x, void* 
     quantize_to_lds<Q4, kMaxP>(v, n, xq, xs, q, s);
 }
 
+// Batched prefill on row shards: token t's slice of n values (whole 128-groups) -> [n int8] at q + t * n, its scales at s + t * (n / 128);
+// the arithmetic of quantize_to_lds, i.e. bit for bit what quantising the gathered vector gives for these groups.
+__global__ __launch_bounds__(kBlock) void quantize_rows_kernel(const float* x, int8_t* q, float* s, int n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int8_t* xq = reinterpret_cast<int8_t*>(smem);
+    float* xs = reinterpret_cast<float*>(smem + ((n + 15) & ~15));
+    const size_t t = blockIdx.x;
+    float4 v[kMaxP];
+    load_vec(v, x + t * n, n);
+    quantize_to_lds<false, kMaxP>(v, n, xq, xs, q + t * n, s + t * (n / kGS));
+}
+hipError_t launch_quantize_rows(const float* x, int n, int n_tok, int8_t* q, float* s, hipStream_t st) {
+    if (n % kGS || n > kMaxP * 1024 || n_tok <= 0) return hipErrorInvalidValue;
+    const size_t smem = ((n + 15) & ~15) + (size_t)(n / kGS + 4) * 4;
+    hipLaunchKernelGGL(quantize_rows_kernel, dim3(n_tok), dim3(kBlock), smem, st, x, q, s, n);
+    return hipGetLastError();
+}
+// ... and the gathered blocks of all shards ([w]: n_tok x n_l int8, then at s_off n_tok x n_l / 128 scales) as the activation operand of the
+// GEMM that follows: xq [n_tok][world * n_l], xs [n_tok][world * n_l / 128].  One workgroup per token; 16 bytes per lane.
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int8_t* xq, float* xs) {
+    const size_t t = blockIdx.x;
+    const int n = world * n_l, gl = n_l / kGS;
+    for (int e = threadIdx.x * 16; e < n; e += kBlock * 16) {
+        const int w = e / n_l, j = e - w * n_l;
+        *reinterpret_cast<i32x4*>(xq + t * n + e) = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(blocks + (size_t)w * blk_stride + t * n_l + j));
+    }
+    for (int g = threadIdx.x; g < n / kGS; g += kBlock) {
+        const int w = g / gl, j = g - w * gl;
+        xs[t * (n / kGS) + g] = __builtin_nontemporal_load(reinterpret_cast<const float*>(blocks + (size_t)w * blk_stride + s_off) + t * gl + j);
+    }
+}
+hipError_t launch_gather_rows(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int n_tok, int8_t* xq, float* xs, hipStream_t st) {
+    if (n_l % kGS || s_off % 16 || blk_stride % 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_tok), dim3(kBlock), 0, st, blocks, blk_stride, s_off, world, n_l, xq, xs);
+    return hipGetLastError();
+}
+
 // The static kernels' quantisers (vec_quantize_q8 / vec_quantize_q4: the prologue code of the decode launches, grouped passes and the
 // ragged Gemma lengths included) behind the same entry point, for the shapes they are built for.
 template <int N, int NTH, bool Q4>
@@ -2316,6 +2353,25 @@ __global__ __launch_bounds__(kBlock) void exchange_push_kernel(const ExchangeArg
     }
     __threadfence_system();
     __syncthreads();
+}
+
+// Blocks of a token batch (hundreds of KB): the copy by as many workgroups as it takes, then the push kernel with nothing left to copy
+// raises the flags (the kernel boundary orders the two; the stores are system-scope visible when the copy kernel has ended).
+__global__ __launch_bounds__(kBlock) void exchange_copy_kernel(const ExchangeArgs a) {
+    const size_t stride = (size_t)gridDim.x * kBlock * 16;
+    for (int w = 0; w < a.world; ++w) {
+        if (w == a.rank) continue;
+        for (size_t off = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 16; off < (size_t)a.bytes; off += stride)
+            __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const i32x4*>(a.local + off)), reinterpret_cast<i32x4*>(a.peer_dst[w] + off));
+    }
+    __threadfence_system();
+}
+hipError_t launch_exchange_copy_push(const ExchangeArgs& a, hipStream_t s) {
+    if (a.qsrc || a.par_bytes || a.bytes % 16) return hipErrorInvalidValue;
+    const int grid = (int)std::min<size_t>(256, ((size_t)a.bytes + kBlock * 16 - 1) / (kBlock * 16));
+    if (grid > 0) LMRS_LAUNCH_GRID(exchange_copy_kernel, dim3(grid), kBlock, 0, s, a);
+    ExchangeArgs f = a; f.bytes = 0;
+    return launch_exchange_push(f, s);
 }
 
 hipError_t launch_exchange_push(const ExchangeArgs& a, hipStream_t s) {

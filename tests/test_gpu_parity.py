@@ -703,7 +703,7 @@ def test_row_sharding_on_random_geometries(L, monkeypatch, i):
     grp.close()
 
 
-def _p2p_rank(rank, world, img_path, cfg, env, q_in, q_out):
+def _p2p_rank(rank, world, img_path, cfg, env, q_in, q_out, n_fill=6, n_prompt=3):
     """One process of the peer-to-peer test: its shard of the model on device 0, handles exchanged through the parent."""
     try:
         import os, sys
@@ -717,32 +717,39 @@ def _p2p_rank(rank, world, img_path, cfg, env, q_in, q_out):
         m = lmrs_amd.Transformer(img, device=0, rank=rank, world=world)          # no communicator id: peer-to-peer transport
         q_out.put((rank, "handle", m.p2p_handle()))
         m.p2p_connect(q_in.get(timeout=120))
-        prompt = S.prompt_tokens(cfg, 6, 44)
+        prompt = S.prompt_tokens(cfg, n_fill, 44)
         emb = m.get_embeddings(prompt)
-        newp = m.fill_kv_cache(emb, 0)                                           # sharded fill_kv_cache: layer segments token by token
-        toks = m.generate_greedy(S.prompt_tokens(cfg, 3, 45), 20, start_pos=newp)   # crosses LMRS_ATT_SPLIT_POS: split attention on shards
-        lg = m.forward(int(toks[-1]), newp + 3 + 19).copy()
-        q_out.put((rank, "done", (emb, newp, toks, lg, m.shard_uses_graph())))
+        newp = m.fill_kv_cache(emb, 0)                                           # sharded fill_kv_cache: batched on row shards where built, else layer segments token by token
+        try: m.last_fill_ms(); batched = True                                     # (only the batched forward_layer records its device time)
+        except Exception: batched = False
+        toks = m.generate_greedy(S.prompt_tokens(cfg, n_prompt, 45), 20, start_pos=newp)   # crosses LMRS_ATT_SPLIT_POS: split attention on shards
+        lg = m.forward(int(toks[-1]), newp + n_prompt + 19).copy()
+        q_out.put((rank, "done", (emb, newp, toks, lg, m.shard_uses_graph(), batched)))
         m.close()
     except Exception:
         import traceback
         q_out.put((rank, "error", traceback.format_exc()))
 
 
-@pytest.mark.parametrize("cfg,world,plan", [("mini-llama", 2, "tp"), ("mini-gemma", 2, "tp"), ("mini-llama3b", 4, "tp"), ("mini-llama", 4, "cls"), ("mini-gemma", 2, "cls")])
-def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan):
+@pytest.mark.parametrize("cfg,world,plan,n_fill,n_prompt", [
+    ("mini-llama", 2, "tp", 6, 3), ("mini-gemma", 2, "tp", 6, 3), ("mini-llama3b", 4, "tp", 6, 3), ("mini-llama", 4, "cls", 6, 3), ("mini-gemma", 2, "cls", 6, 3),
+    ("mini-llama", 2, "tp-tokenwise", 6, 3),          # LMRS_NO_BATCHED_PREFILL: the row shards' token-by-token fill_kv_cache
+    ("mini-llama", 2, "tp", 70, 12), ("mini-llama3b", 4, "tp", 70, 12), ("mini-phi", 2, "tp", 40, 9)])     # batched forward_layer on row shards, block attention, batched prompt
+def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan, n_fill, n_prompt):
     """The multi-GPU launch shape on a one-GPU box: `world` PROCESSES, one shard each (here all on device 0), exchange arenas opened
     through IPC handles, every exchange a push kernel that really waits for the other process's flag.  fill_kv_cache on the shards,
     greedy decoding across the split-attention switch, full logits on every rank - all bit-equal to the CPU path.  plan "tp": the
     layers' matrices row-split (exchanges inside every layer); "cls": whole layers on every shard, the classifier split (one exchange
-    per token)."""
+    per token).  Plan "tp" with Q8_0 Llama / Phi shapes runs fill_kv_cache and the prompt of generate_greedy as forward_layer over the token
+    batch on every shard (prefill_layers_tp: two all-gathers of quantised token-batch blocks per layer)."""
     import multiprocessing as mp
     img = S.build_image(cfg, S.Q8_0, seed=43)
     path = str(tmp_path / "m.lmrs"); img.tofile(path)
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue(); q_in = [ctx.Queue() for _ in range(world)]
-    env = {"LMRS_ATT_SPLIT_POS": "16", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LMRS_P2P_TIMEOUT_MS": "1500", "LMRS_SHARD_PLAN": plan}
-    procs = [ctx.Process(target=_p2p_rank, args=(r, world, path, cfg, env, q_in[r], q_out)) for r in range(world)]
+    env = {"LMRS_ATT_SPLIT_POS": "16", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LMRS_P2P_TIMEOUT_MS": "1500", "LMRS_SHARD_PLAN": plan.split("-")[0]}
+    if plan.endswith("tokenwise"): env["LMRS_NO_BATCHED_PREFILL"] = "1"
+    procs = [ctx.Process(target=_p2p_rank, args=(r, world, path, cfg, env, q_in[r], q_out, n_fill, n_prompt)) for r in range(world)]
     for p in procs: p.start()
     try:
         handles = {}
@@ -761,13 +768,14 @@ def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan
         for p in procs:
             if p.is_alive(): p.kill()
     orc = O.Oracle(img)
-    prompt = S.prompt_tokens(cfg, 6, 44)
+    prompt = S.prompt_tokens(cfg, n_fill, 44)
     e_ref = orc.get_embeddings(prompt); p_ref = orc.fill_kv_cache(e_ref, 0)
-    t_ref = orc.generate_greedy(S.prompt_tokens(cfg, 3, 45), 20, start_pos=p_ref)
-    l_ref = orc.forward(int(t_ref[-1]), p_ref + 3 + 19)
+    t_ref = orc.generate_greedy(S.prompt_tokens(cfg, n_prompt, 45), 20, start_pos=p_ref)
+    l_ref = orc.forward(int(t_ref[-1]), p_ref + n_prompt + 19)
     for r in range(world):
-        emb, newp, toks, lg, graph = res[r]
+        emb, newp, toks, lg, graph, batched = res[r]
         assert newp == p_ref
+        assert batched == (plan == "cls" or (plan == "tp" and cfg != "mini-gemma")), f"rank {r}: fill_kv_cache took the {'batched' if batched else 'token-by-token'} path"
         assert_bit_equal(emb, e_ref, f"rank {r}: embeddings after the sharded fill_kv_cache")
         assert (toks == t_ref).all(), (r, toks, t_ref)
         assert_bit_equal(lg, l_ref, f"rank {r}: logits")

@@ -1238,6 +1238,19 @@ static int self_check(Problem& p, const char* name) {
     return bad != 0;
 }
 
+#ifdef NARROW
+// -DNARROW (gemmpipe_narrow): the LDS-DMA ring kernel (the product's) over SMALL workgroup tiles, for the launches that leave CUs idle - wo / w2 / qkv at
+// 128-256 tokens are 64-192 workgroups of 64 x 64 on 256 CUs, every one of them bound by its own DMA issue (16 KiB per group at ~70 cycles per KiB piece)
+#define VARIANTS(X)                                                           \
+    X(2, 2, 2, 2, 0, " 64 x  64, 4 waves (32 x 32), ring       ")           \
+    X(2, 1, 2, 4, 0, " 64 x  64, 8 waves (32 x 16), ring       ")           \
+    X(2, 1, 2, 2, 0, " 64 x  32, 4 waves (32 x 16), ring       ")           \
+    X(1, 2, 2, 2, 0, " 32 x  64, 4 waves (16 x 32), ring       ")           \
+    X(2, 2, 1, 2, 0, " 32 x  64, 2 waves (32 x 32), ring       ")           \
+    X(1, 1, 2, 2, 0, " 32 x  32, 4 waves (16 x 16), ring       ")           \
+    X(2, 1, 1, 2, 0, " 32 x  32, 2 waves (32 x 16), ring       ")           \
+    X(1, 2, 4, 1, 0, " 64 x  32, 4 waves (16 x 32), ring       ")
+#else
 #define VARIANTS(X)                                                           \
     X(2, 2, 2, 2, 2048, " 64 x  64, 4 waves, one block            ")           \
     X(2, 2, 2, 2, 2112, " 64 x  64, 4 waves, 1 blk, split pairs   ")           \
@@ -1254,6 +1267,7 @@ static int self_check(Problem& p, const char* name) {
     X(4, 4, 4, 2, 2053, "256 x 128, 8 waves, MFMA+READS           ")           \
     X(4, 4, 4, 2, 2117, "256 x 128, 8 waves, MFMA+READS, split    ")           \
     X(4, 4, 4, 2, 2181, "256 x 128, 8 waves, MFMA+READS, NO BARR. ")
+#endif
 
 int main(int argc, char** argv) {
     HIPC(hipSetDevice(0));
@@ -1275,11 +1289,16 @@ int main(int argc, char** argv) {
     }
     const int reps = pmc ? 1 : quick ? 5 : 20;
     struct Shape { int K, o, n_tok; const char* what; };
+#ifdef NARROW
+    const Shape shapes[] = {{8192, 2048, 256, "w2 of Llama-3.2-1B, 256 tokens"}, {8192, 2048, 128, "w2, 128 tokens"}, {2048, 2048, 256, "wo, 256 tokens"}, {2048, 2048, 128, "wo, 128 tokens"},
+                            {2048, 3072, 256, "qkv, 256 tokens"}, {2048, 3072, 128, "qkv, 128 tokens"}, {2048, 16384, 128, "w1/w3, 128 tokens"}, {8192, 2048, 512, "w2, 512 tokens"}, {8192, 3072, 320, "w2 of Phi-3.5, 320 tokens"}};
+#else
     const Shape shapes[] = {{2048, 16384, 512, "w1/w3 of Llama-3.2-1B, 512 tokens"}, {2048, 16384, 256, "w1/w3, 256 tokens"}, {2048, 16384, 2048, "w1/w3, 2048 tokens"},
                             {8192, 2048, 512, "w2 of Llama-3.2-1B, 512 tokens"}, {8192, 2048, 256, "w2, 256 tokens"},
                             {2048, 3072, 512, "qkv of Llama-3.2-1B, 512 tokens"}, {2048, 3072, 256, "qkv, 256 tokens"},
                             {2048, 2048, 512, "wo of Llama-3.2-1B, 512 tokens"}, {2048, 2048, 256, "wo, 256 tokens"},
                             {1024, 4096, 1154, "CLIP fc1 (2 crops x 577 rows)"}, {4096, 1024, 1154, "CLIP fc2"}};
+#endif
     for (const Shape& sh : shapes) {
         if (pmc && !((sh.o == 16384 && sh.n_tok == 512) || (sh.K == 8192 && sh.n_tok == 512))) continue;
         Problem p(sh.K, sh.o, sh.n_tok, false);

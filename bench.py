@@ -458,7 +458,7 @@ def main():
                            # the same without the upload of the embeddings and the download of the residual stream (HIP events inside the call)
                            "ms_device": round(best_dev * 1e3, 3), "frac_device": round(2 * macs / best_dev / 1e12 / 3944.0, 4),
                            "kernel": "lmrs::gemm_q8_*_kernel (v_mfma_i32_16x16x64_i8" + ("; Q4_0 weights unpacked to signed bytes per fragment" if args.qtype == "q4_0" else "") + ") + per-token rows + "
-                                     + ("the per-token attention body (Gemma-2)" if cfg.model_type == S.GEMMA else "block attention")
+                                     + ("block attention (256-wide heads, soft-capped scores: Gemma-2)" if cfg.model_type == S.GEMMA else "block attention")
                                      + "; `ms` / `frac` include the host<->device copies of the embeddings, `ms_device` / `frac_device` do not"}
             # ---- BASELINE configs[4]: the image path in the reference's call order (chat.rs:84-121) - CLIP tower over the global crop and
             # one sub-image (2 crops x 577 tokens x 23 of 24 layers), projector, fill_kv_cache over the 4 + 313 + 3 embeddings

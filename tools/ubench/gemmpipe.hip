@@ -1238,7 +1238,7 @@ static int self_check(Problem& p, const char* name) {
     return bad != 0;
 }
 
-#ifdef NARROW
+#if defined(NARROW)
 // -DNARROW (gemmpipe_narrow): the LDS-DMA ring kernel (the product's) over SMALL workgroup tiles, for the launches that leave CUs idle - wo / w2 / qkv at
 // 128-256 tokens are 64-192 workgroups of 64 x 64 on 256 CUs, every one of them bound by its own DMA issue (16 KiB per group at ~70 cycles per KiB piece)
 #define VARIANTS(X)                                                           \
@@ -1250,6 +1250,19 @@ static int self_check(Problem& p, const char* name) {
     X(1, 1, 2, 2, 0, " 32 x  32, 4 waves (16 x 16), ring       ")           \
     X(2, 1, 1, 2, 0, " 32 x  32, 2 waves (32 x 16), ring       ")           \
     X(1, 2, 4, 1, 0, " 64 x  32, 4 waves (16 x 32), ring       ")
+#elif defined(MANYWAVE)
+// -DMANYWAVE (gemmpipe_manywave): the big tiles cut into MORE waves (16 per workgroup, four per SIMD) - less work per wave and iteration, more waves to hide a
+// wave's own load -> barrier -> fragment reads -> MFMAs -> combine chain behind
+#define VARIANTS(X)                                                           \
+    X(4, 4, 4, 2, 0, "256 x 128,  8 waves (64 x 64), ring      ")           \
+    X(2, 4, 8, 2, 0, "256 x 128, 16 waves (32 x 64), ring      ")           \
+    X(4, 2, 4, 4, 0, "256 x 128, 16 waves (64 x 32), ring      ")           \
+    X(2, 4, 4, 2, 0, "128 x 128,  8 waves (32 x 64), ring      ")           \
+    X(2, 2, 4, 4, 0, "128 x 128, 16 waves (32 x 32), ring      ")           \
+    X(1, 4, 8, 2, 0, "128 x 128, 16 waves (16 x 64), ring      ")           \
+    X(2, 2, 4, 2, 0, "128 x  64,  8 waves (32 x 32), ring      ")           \
+    X(2, 1, 2, 4, 0, " 64 x  64,  8 waves (32 x 16), ring      ")           \
+    X(1, 1, 4, 4, 0, " 64 x  64, 16 waves (16 x 16), ring      ")
 #else
 #define VARIANTS(X)                                                           \
     X(2, 2, 2, 2, 2048, " 64 x  64, 4 waves, one block            ")           \
@@ -1289,7 +1302,10 @@ int main(int argc, char** argv) {
     }
     const int reps = pmc ? 1 : quick ? 5 : 20;
     struct Shape { int K, o, n_tok; const char* what; };
-#ifdef NARROW
+#ifdef MANYWAVE
+    const Shape shapes[] = {{2048, 16384, 512, "w1/w3 of Llama-3.2-1B, 512 tokens"}, {2048, 16384, 256, "w1/w3, 256 tokens"}, {3072, 16384, 512, "w1/w3 of Llama-3.2-3B, 512 tokens"},
+                            {8192, 2048, 512, "w2 of Llama-3.2-1B, 512 tokens"}, {2048, 3072, 512, "qkv, 512 tokens"}, {1024, 4096, 1154, "CLIP fc1 (2 crops x 577 rows)"}, {4096, 1024, 1154, "CLIP fc2"}};
+#elif defined(NARROW)
     const Shape shapes[] = {{8192, 2048, 256, "w2 of Llama-3.2-1B, 256 tokens"}, {8192, 2048, 128, "w2, 128 tokens"}, {2048, 2048, 256, "wo, 256 tokens"}, {2048, 2048, 128, "wo, 128 tokens"},
                             {2048, 3072, 256, "qkv, 256 tokens"}, {2048, 3072, 128, "qkv, 128 tokens"}, {2048, 16384, 128, "w1/w3, 128 tokens"}, {8192, 2048, 512, "w2, 512 tokens"}, {8192, 3072, 320, "w2 of Phi-3.5, 320 tokens"}};
 #else

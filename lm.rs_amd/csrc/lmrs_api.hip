@@ -1260,7 +1260,7 @@ static int prefill_alloc(lmrs_ctx* c) {
     if (c->pf_ready) return 0;
     const lmrs_args& a = c->args;
     const size_t B = kPrefillTokens, wide = std::max<size_t>(std::max<size_t>(a.dim, a.hidden_dim), (size_t)std::max(c->att_dim, c->att_full));
-    const bool own_blocks = c->world > 1 && !c->cls_only && !c->pfx_att;        // (peer-to-peer shards: the blocks are part of the exchange arena)
+    const bool own_blocks = (c->world > 1 || c->comm) && !c->cls_only && !c->pfx_att;        // (peer-to-peer shards: the blocks are part of the exchange arena)
     if (own_blocks) { c->pfb_att = prefill_tp_block((size_t)c->att_dim); c->pfb_h = prefill_tp_block((size_t)c->hid_l); c->pfx_owned = true; }
     struct Want { void** p; size_t bytes; } want[] = {
         {reinterpret_cast<void**>(&c->pf_x), B * a.dim * 4}, {reinterpret_cast<void**>(&c->pf_q), B * c->att_dim * 4},
@@ -1392,9 +1392,11 @@ static int prefill_layers_tp(lmrs_ctx* c, int m, int p0) {
     }
     return 0;
 }
-static bool prefill_tp_ok(const lmrs_ctx* c) { return c->world > 1 && (c->comm || (c->p2p && c->p2p_ready)) && prefill_tp_shapes_ok(c); }
+// (a communicator of ONE rank counts as a row-sharded context - the RCCL branch of the batched path can then run, and be tested, on a one-GPU box)
+static bool row_sharded(const lmrs_ctx* c) { return (c->world > 1 || c->comm) && !c->cls_only; }
+static bool prefill_tp_ok(const lmrs_ctx* c) { return row_sharded(c) && (c->comm || (c->p2p && c->p2p_ready)) && prefill_tp_shapes_ok(c); }
 static int prefill_pass(lmrs_ctx* c, int m, int p0) {
-    if (c->world > 1 && !c->cls_only) { c->ex_slot = 0; return prefill_layers_tp(c, m, p0); }
+    if (row_sharded(c)) { c->ex_slot = 0; return prefill_layers_tp(c, m, p0); }
     return prefill_layers(c, m, p0);
 }
 

@@ -870,6 +870,15 @@ def test_rccl_path_with_one_rank(L):
     o2 = O.Oracle(img)
     for pos, t in enumerate(prompt):
         assert_bit_equal(m.forward(int(t), pos), o2.forward(int(t), pos), f"rccl world=1 logits at pos {pos}")
+    # the batched forward_layer of a row-sharded context over RCCL (prefill_layers_tp: quantised token-batch blocks, ncclAllGather in place, gather
+    # kernel) - one rank is all a one-GPU box can give RCCL, but it is the same code: fill_kv_cache of 70 tokens, then a 12-token prompt
+    toks = S.prompt_tokens("mini-llama", 70, 33)
+    a = m.get_embeddings(toks); b = o2.get_embeddings(toks)
+    assert m.fill_kv_cache(a, 4) == o2.fill_kv_cache(b, 4) == 74
+    assert m.last_fill_ms() > 0                                             # (only the batched path records its device time)
+    assert_bit_equal(a, b, "rccl world=1: residual stream after the batched layers")
+    p2 = S.prompt_tokens("mini-llama", 12, 34)
+    assert (m.generate_greedy(p2, 8, start_pos=74) == o2.generate_greedy(p2, 8, start_pos=74)).all()
 
 
 @pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q8_0), ("mini-llama3b", S.Q8_0), ("mini-phi", S.Q8_0), ("mini-gemma", S.Q8_0),

@@ -11,7 +11,7 @@
 #   prefill N  fill_kv_cache(N) rate + rocprofv3 kernel statistics
 #   vision     CLIP tower rate + rocprofv3 kernel statistics
 #   ab "..."   tools/ab_bench.py with the quoted arguments
-#   crash M Q  rocprofv3 probes: with / without kernel-argument preload (liblmrs_hip_nokp.so), 1 / 4 steps per graph launch
+#   crash M Q  rocprofv3 probes: with / without kernel-argument preload (build the second library first: make -C lm.rs_amd/csrc V=nokp KPRELOAD=), 1 / 4 steps per graph launch
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"

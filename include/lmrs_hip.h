@@ -201,6 +201,10 @@ int lmrs_debug_inject(lmrs_ctx* ctx, int what, int a, int b);
 /* Number of kernel launches per decode step and the sum of algorithmic bytes per step at `pos` (the byte model of SURVEY.md §8d;
  * measurement aid, no reference counterpart). */
 int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* algo_bytes);
+/* The output tile (weight rows x tokens per workgroup, waves per workgroup) the batched matmul_q8 / matmul_q4 (functional.rs:173-250 with
+ * sl = n_tok) runs a launch of `o` rows over K = `n` with: the cost model of DESIGN.md section 4.1, host arithmetic only (no device is
+ * touched).  0 x 0: fewer than 48 tokens - the direct kernels.  Inspection aid, no reference counterpart. */
+int lmrs_debug_gemm_tile(uint32_t n, uint32_t o, uint32_t n_tok, int q4, int* tile_rows, int* tile_tokens, int* waves);
 
 /* ---- CLIP image tower of the multimodal models  (src/vision.rs) ---------------------------
  * lmrs_vision_create   <- VisionTransformer::new(data) -> (VisionTransformer, usize)   vision.rs:99-243

@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv", "lmrs_debug_inject", "lmrs_last_fill_ms",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv", "lmrs_debug_inject", "lmrs_last_fill_ms", "lmrs_debug_gemm_tile",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_comm_ranks", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
@@ -128,6 +128,7 @@ def lib():
         L.lmrs_debug_kv.argtypes = [vp, C.c_int, u32, u32, vp]
         L.lmrs_debug_inject.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.lmrs_last_fill_ms.argtypes = [vp, C.POINTER(C.c_double)]
+        L.lmrs_debug_gemm_tile.argtypes = [u32, u32, u32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.lmrs_p2p_handle.argtypes = [vp, vp]
         L.lmrs_p2p_connect.argtypes = [vp, vp]
         L.lmrs_bench_step.argtypes = [vp, u32, C.c_int, vp, vp, vp]
@@ -423,6 +424,14 @@ def rope_terms(model_type: int, rope_theta: float, head_size: int, pos: int, j: 
     c, s_ = C.c_float(), C.c_float()
     _chk(lib().lmrs_rope_terms(C.byref(a), pos, j, C.byref(c), C.byref(s_)))
     return np.float32(c.value), np.float32(s_.value)
+
+
+def gemm_tile(n: int, o: int, n_tok: int, q4: bool = False):
+    """(weight rows, tokens, waves) of the workgroup tile the batched matmul_q8 / matmul_q4 runs this launch with (host arithmetic only, no GPU);
+    (0, 0, 0) below 48 tokens: the direct kernels (lmrs_debug_gemm_tile)."""
+    tm, tn, w = C.c_int(), C.c_int(), C.c_int()
+    _chk(lib().lmrs_debug_gemm_tile(n, o, n_tok, int(bool(q4)), C.byref(tm), C.byref(tn), C.byref(w)))
+    return tm.value, tn.value, w.value
 
 
 def processor_hd_transform(out_patches: np.ndarray, w_crop: int, h_crop: int, glb_gn: np.ndarray, sub_gn: np.ndarray) -> np.ndarray:

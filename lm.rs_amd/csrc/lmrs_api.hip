@@ -1696,6 +1696,14 @@ extern "C" int lmrs_debug_inject(lmrs_ctx* c, int what, int a, int b) {
     return fail("unknown injection");
 }
 
+extern "C" int lmrs_debug_gemm_tile(uint32_t n, uint32_t o, uint32_t n_tok, int q4, int* tile_rows, int* tile_tokens, int* waves) {
+    if (!tile_rows || !tile_tokens || !waves) return fail("NULL argument");
+    if (n == 0 || n % 256 || o == 0 || o % 16 || n_tok == 0) return fail("lmrs_debug_gemm_tile: n must be a positive multiple of 256, o of 16");
+    *tile_rows = *tile_tokens = *waves = 0;                      // below 48 tokens: the direct kernels (a token tile would be mostly padding)
+    if (n_tok >= 48) { const GemmTile t = gemm_q8_ring_tile((int)n, (int)o, (int)n_tok, q4 != 0); *tile_rows = t.tm; *tile_tokens = t.tn; *waves = t.waves; }
+    return 0;
+}
+
 extern "C" int lmrs_step_info(const lmrs_ctx* c, uint32_t pos, int* n_launches, double* algo_bytes) {
     if (!c) return fail("ctx is NULL");
     const lmrs_args& a = c->args;

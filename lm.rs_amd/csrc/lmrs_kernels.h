@@ -172,6 +172,8 @@ struct GemmArgs {
     const float* bias; const float* resid; float qscale;                         // CLIP epilogues: bias [o], residual [n_tok][o], sqrt(head_size)
 };
 hipError_t launch_gemm_q8(const GemmArgs& a, int epi, hipStream_t s);
+struct GemmTile { int tm, tn, waves; };                                        // weight rows x tokens of a workgroup's output tile, waves per workgroup
+GemmTile gemm_q8_ring_tile(int n, int o, int n_tok, bool q4);                   // host only: the LDS-DMA ring kernel's tile for a launch of >= 48 tokens
 hipError_t launch_matmul_f32_rows(const GemmArgs& a, int epi, hipStream_t s);   // q_type None sections of the image path (lmrs_f32.inc)
 bool rows_prologue_supported(int n);
 hipError_t launch_rows_prologue(float* x, const float* rms_w, const float* delta, const float* add_w, float eps, int add_unit, int mode, int q4,

@@ -128,3 +128,27 @@ def test_rope_table_terms_on_the_host(model_type, theta, hs):
             c, s_ = lmrs_amd.rope_terms(model_type, theta, hs, pos, j)
             rc, rs = NR.NumpyModel.rope(ref, pos, j)
             assert np.float32(c).view(np.uint32) == np.float32(rc).view(np.uint32) and np.float32(s_).view(np.uint32) == np.float32(rs).view(np.uint32), (pos, j, c, rc, s_, rs)
+
+
+def test_gemm_tile_choice_for_the_baseline_shapes():
+    """The tile the batched int8-MFMA GEMM takes per launch (DESIGN.md section 4.1's table; host arithmetic of the library's cost model,
+    lmrs_debug_gemm_tile).  Pinned so that a change of the model shows up as a change of this table."""
+    import lmrs_amd
+    t = lmrs_amd.gemm_tile
+    # Llama-3.2-1B: w1/w3 (16384 rows, K 2048), qkv (3072), wo (2048, K 2048), w2 (2048, K 8192)
+    assert t(2048, 16384, 512) == (256, 128, 8) and t(2048, 16384, 256) == (128, 128, 8)
+    assert t(2048, 3072, 512) == (96, 64, 4) and t(2048, 3072, 256) == (64, 64, 8) and t(2048, 3072, 128) == (64, 32, 4)
+    assert t(2048, 2048, 512) == (64, 64, 8) and t(8192, 2048, 512) == (64, 64, 8)
+    assert t(2048, 2048, 256) == (64, 32, 4) and t(8192, 2048, 256) == (64, 32, 4)
+    assert t(2048, 2048, 128) == (32, 32, 4) and t(8192, 2048, 128) == (32, 32, 4)
+    # the 3072-wide models: wo / w2 at 512 tokens in one round of 128 x 64 tiles; Phi-3.5's 320 embeddings fit one round of 64 x 64
+    assert t(3072, 3072, 512) == (128, 64, 8) and t(8192, 3072, 512) == (128, 64, 8) and t(8192, 3072, 320) == (64, 64, 8)
+    assert t(3072, 16384, 512) == (256, 128, 8)
+    # CLIP tower, 2 crops x 577 tokens: qkv, out_proj, fc1, fc2
+    assert t(1024, 3072, 1154) == (128, 128, 8) and t(1024, 1024, 1154) == (128, 64, 8)
+    assert t(1024, 4096, 1154) == (256, 128, 8) and t(4096, 1024, 1154) == (128, 64, 8)
+    # Gemma-2-2B Q4_0: under-filled wo / w2 on 64 x 32, the gate / up pairs on 256 x 128
+    assert t(2048, 2304, 256, q4=True) == (64, 32, 4) and t(9216, 2304, 256, q4=True) == (64, 32, 4) and t(2304, 18432, 256, q4=True) == (256, 128, 8)
+    assert t(2048, 2048, 47) == (0, 0, 0)                                   # below 48 tokens: the direct kernels
+    with pytest.raises(Exception): t(2000, 2048, 64)
+

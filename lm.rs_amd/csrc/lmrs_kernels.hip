@@ -1806,6 +1806,257 @@ __device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int 
     if (a.dbg && lane == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The wave form for 64-wide heads with TWO waves per head from position 64 on (contexts up to 128: Llama-3.2-1B).  Below 64 positions wave 1
+// leaves at once and wave 0 runs the head exactly as attention_wave_tag does.  From 64 on the head's work is cut by KEY RANGE - wave w owns keys
+// 64 w .. 64 w + 63: their K tile rows (LDS-DMA), their value rows (registers: 64 buffer loads per wave instead of 128 in one - the prefetch of a
+// 100-position context used to land 2.6 us after launch, later than the last qkv row), their scores and exponentials - and the reference's
+// sequential chains cross the waves in order through LDS: the maximum (order-free), the softmax sum (wave 0's 64 terms, then wave 1 continues
+// from its partial), and the value chain o += a_t v_t: wave 0 adds its 64 terms while wave 1 forms the PRODUCTS a_t v_t of its keys (the
+// multiplies are independent - only the adds are the chain) and parks them in LDS; wave 0 then adds them in key order.  Both waves poll q / k / v
+// and rotate q for themselves (no hand-off before the scores); wave 0 alone writes the rotated key to the cache.  Four lds_barrier()s between
+// two waves when both are alive, none otherwise.  Same adds in the same order as every other form: bit-equal.
+// ------------------------------------------------------------------------------------------------
+constexpr size_t kPairSmem = (size_t)(2 * 2 * 64 + 128 + 16 + 16) * 4 + (size_t)16 * 128 * 16 + (size_t)64 * 64 * 4;   // q / k per wave, weights, hand-off words, K tile, products
+template <bool GEMMA>
+__device__ __forceinline__ void attention_pair_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
+    constexpr int HS = 64, HS4 = 16, TW = 128, half = 32;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool two = pos >= 64;                                     // (uniform over the workgroup)
+    if (wv > (two ? 1 : 0)) return;
+    const int tb = two ? 64 * wv : 0;                               // first key of this wave
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul, kv_dim = a.n_kv_heads * HS;
+    const int T = pos + 1, S = a.seq_len;
+    float* base = reinterpret_cast<float*>(smem);
+    float* qs = base + wv * 2 * HS;                                 // this wave's rotated query
+    float* kn = qs + HS;                                            // ... raw, then rotated key of this position
+    float* att = base + 4 * HS;                                     // TW + 16 weights (shared)
+    float* red = att + TW + 16;                                     // 16 hand-off words: [0..1] maxima, [2] wave 0's sum, [3] the sum, [4] a_pos
+    float4* kt = reinterpret_cast<float4*>(red + 16);               // [HS4][TW] x 16 bytes (shared)
+    float* prod = reinterpret_cast<float*>(kt + HS4 * TW);          // [64 keys of wave 1][HS]: a_t * v_t
+    float* kT = att_k_head(a, kvh, HS);
+    const float* vbase = a.v_cache + (size_t)a.layer * S * kv_dim + kvh * HS;
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[0] = wall_clock64();
+
+    const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + (lane < half ? lane : 0)) * 2);
+    if (tb < pos) {                                                 // this wave's 64 keys by LDS-DMA (rows past the sequence are read as they lie in the cache: seq_len >= 128)
+#pragma unroll
+        for (int g = 0; g < HS4; ++g)
+            __builtin_amdgcn_global_load_lds((const LMRS_GLOBAL void*)(kT + ((size_t)g * S + tb + lane) * 4),
+                                             (__attribute__((address_space(3))) void*)(kt + g * TW + tb), 16, 0, 0);
+    }
+    // this wave's value rows: v[u] = v_{tb + u}[lane], blocks of 16 rows nested so that the prefetch has one join (see attention_wave_tag)
+    float v[64];
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vbase), 0, 0x7fffffff, 0x00020000);
+    const int vrow = kv_dim * 4, vb0 = tb * vrow;
+    auto vblock = [&](auto self, auto u0c) __attribute__((always_inline)) -> void {
+        constexpr int u0 = decltype(u0c)::value;
+        if constexpr (u0 < 64) {
+            if (tb + u0 < pos) {                                    // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u0 + u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vrs, lane * 4, vb0 + (u0 + u) * vrow, 0));
+                self(self, std::integral_constant<int, u0 + 16>());
+            }
+        }
+    };
+    vblock(vblock, std::integral_constant<int, 0>());
+#pragma unroll
+    for (int u = 0; u < 64; ++u) { v[u] = tb + u < pos ? v[u] : 0.0f; asm volatile("" : "+v"(v[u])); }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[1] = wall_clock64();
+
+    // ---- q, raw k, v of this position: poll the granules (both waves: no hand-off before the scores)
+    unsigned long long xg[3];
+    {
+        const unsigned long long* gp[3] = {tg.gran + h * HS + lane, tg.gran + tg.att_dim + kvh * HS + lane, tg.gran + tg.att_dim + tg.kv_dim + kvh * HS + lane};
+        auto sweep = [&](unsigned long long (&x)[3]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[k] = __hip_atomic_load(gp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto fresh = [&](const unsigned long long (&x)[3]) __attribute__((always_inline)) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ok = ok && (unsigned)(x[k] >> 32) == tg.tag;
+            return __all(ok) != 0;
+        };
+        unsigned long long xa[3], xb[3];
+        sweep(xa);
+        for (unsigned spins = 0;; ++spins) {
+            sweep(xb);
+            if (fresh(xa)) { xg[0] = xa[0]; xg[1] = xa[1]; xg[2] = xa[2]; break; }
+            sweep(xa);
+            if (fresh(xb)) { xg[0] = xb[0]; xg[1] = xb[1]; xg[2] = xb[2]; break; }
+            if (spins > kTagSpinMax || (spins & 1023) == 1023) {     // bounded: report and finish with garbage instead of hanging
+                const int e = __hip_atomic_load(tg.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e != 0 || spins > kTagSpinMax) {
+                    if (e == 0) __hip_atomic_store(tg.err, a.layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xg[0] = xb[0]; xg[1] = xb[1]; xg[2] = xb[2];
+                    break;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (loads return in order: the key tile's DMA landed before the granules did)
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[2] = wall_clock64();
+    const float vnew = __uint_as_float((unsigned)xg[2]);
+    qs[lane] = __uint_as_float((unsigned)xg[0]); kn[lane] = __uint_as_float((unsigned)xg[1]);
+    // RoPE (transformer.rs:480-491): lane j < 32 owns pair (j, j + 32); wave 0 stores the rotated key into the cache, the wave that owns
+    // position `pos` into the LDS tile
+    if (lane < half) {
+        const int j = lane;
+        const float fcr = cs.x, fci = cs.y;
+        {
+            const float v0 = qs[j], v1 = qs[j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            qs[j] = a0 - a1; qs[j + half] = b0 + b1;
+        }
+        const float v0 = kn[j], v1 = kn[j + half];
+        const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+        const float r0 = a0 - a1, r1 = b0 + b1;
+        if (wv == 0) {
+            kT[(((size_t)(j >> 2) * S + pos) << 2) + (j & 3)] = r0;
+            kT[(((size_t)((j + half) >> 2) * S + pos) << 2) + ((j + half) & 3)] = r1;
+        }
+        if ((pos >> 6) == (two ? wv : 0)) {
+            reinterpret_cast<float*>(kt)[(((j >> 2) * TW + pos) << 2) + (j & 3)] = r0;
+            reinterpret_cast<float*>(kt)[((((j + half) >> 2) * TW + pos) << 2) + ((j + half) & 3)] = r1;
+        }
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[3] = wall_clock64();
+
+    // ---- scores (transformer.rs:507-529): one lane per key of this wave, sequential dot over the head dims
+    int wpos = pos;
+    if constexpr (GEMMA) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
+    const float sqrt_hs = sqrtf((float)HS), ninf = __uint_as_float(0xff800000u);
+    const int t = tb + lane;
+    float sc;
+    {
+        float score = 0.0f;
+        constexpr int GB = 4;
+        float4 ka[GB], qa[GB], kb[GB], qb[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) { ka[u] = kt[u * TW + t]; qa[u] = reinterpret_cast<const float4*>(qs)[u]; }
+#pragma unroll
+        for (int g0 = 0; g0 < HS4; g0 += 2 * GB) {
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { kb[u] = kt[(g0 + GB + u) * TW + t]; qb[u] = reinterpret_cast<const float4*>(qs)[g0 + GB + u]; }
+            asm volatile("" : "+v"(score) : : "memory");
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                float pr;
+                pr = qa[u].x * ka[u].x; score = score + pr;
+                pr = qa[u].y * ka[u].y; score = score + pr;
+                pr = qa[u].z * ka[u].z; score = score + pr;
+                pr = qa[u].w * ka[u].w; score = score + pr;
+            }
+            if (g0 + 2 * GB < HS4) {
+#pragma unroll
+                for (int u = 0; u < GB; ++u) { ka[u] = kt[(g0 + 2 * GB + u) * TW + t]; qa[u] = reinterpret_cast<const float4*>(qs)[g0 + 2 * GB + u]; }
+            }
+            asm volatile("" : "+v"(score) : : "memory");
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                float pr;
+                pr = qb[u].x * kb[u].x; score = score + pr;
+                pr = qb[u].y * kb[u].y; score = score + pr;
+                pr = qb[u].z * kb[u].z; score = score + pr;
+                pr = qb[u].w * kb[u].w; score = score + pr;
+            }
+        }
+        score = score / sqrt_hs;
+        if constexpr (GEMMA) {                                      // transformer.rs:518-526
+            score = score / 50.0f;
+            score = (float)tanh((double)score);
+            score = score * 50.0f;
+            score = score + (((unsigned)(wpos - t) <= 4096u) ? 0.0f : -2.3819763e38f);
+        }
+        sc = t < T ? score : ninf;
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[4] = wall_clock64();
+    // ---- softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
+    float mx = wave64_max(sc);
+    if (two) {
+        if (lane == 0) red[wv] = mx;
+        lds_barrier();
+        mx = fmaxf(red[0], red[1]);
+    }
+    const float e0 = expf_glibc_t(t < T ? sc - mx : 0.0f, etab);
+    const float ex = t < T ? e0 : 0.0f;                             // the lanes past T hold +0.0 (exact: the running sum is >= +0)
+    float sum;
+    if (!two) {
+        sum = wave_serial_sum(0.0f, ex, (T + 15) >> 4);
+    } else {
+        if (wv == 0) { sum = wave_serial_sum(0.0f, ex, 4); if (lane == 0) red[2] = sum; }
+        lds_barrier();
+        if (wv == 1) { sum = wave_serial_sum(red[2], ex, (T - 64 + 15) >> 4); if (lane == 0) red[3] = sum; }
+        lds_barrier();
+        sum = red[3];
+    }
+    const float w = ex / sum;
+    att[t] = t < pos ? w : 0.0f;                                    // the chains below cover the earlier positions; this one follows from registers
+    const bool own_pos = (pos >> 6) == (two ? wv : 0);
+    float a_pos = 0.0f;
+    if (own_pos) a_pos = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), pos & 63));
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[5] = wall_clock64();
+    // ---- weighted sum of values (transformer.rs:533-541), t ascending; lane = output dim
+    if (two && wv == 1) {                                           // the products of this wave's keys, for wave 0 to add in order
+        if (lane == 0) red[4] = a_pos;
+#pragma unroll
+        for (int u0 = 0; u0 < 64; u0 += 16) {
+            if (64 + u0 < pos) {                                    // wave-uniform
+                float4 w4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w4[u] = reinterpret_cast<const float4*>(att)[(64 + u0) / 4 + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    prod[(u0 + 4 * u + 0) * HS + lane] = w4[u].x * v[u0 + 4 * u + 0];
+                    prod[(u0 + 4 * u + 1) * HS + lane] = w4[u].y * v[u0 + 4 * u + 1];
+                    prod[(u0 + 4 * u + 2) * HS + lane] = w4[u].z * v[u0 + 4 * u + 2];
+                    prod[(u0 + 4 * u + 3) * HS + lane] = w4[u].w * v[u0 + 4 * u + 3];
+                }
+            }
+        }
+        lds_barrier();
+        return;
+    }
+    float o = 0.0f;
+#pragma unroll
+    for (int u0 = 0; u0 < 64; u0 += 16) {
+        if (u0 < pos) {                                             // wave-uniform
+            float4 w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w4[u] = reinterpret_cast<const float4*>(att)[u0 / 4 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float pr;
+                pr = w4[u].x * v[u0 + 4 * u + 0]; o = o + pr;
+                pr = w4[u].y * v[u0 + 4 * u + 1]; o = o + pr;
+                pr = w4[u].z * v[u0 + 4 * u + 2]; o = o + pr;
+                pr = w4[u].w * v[u0 + 4 * u + 3]; o = o + pr;
+            }
+        }
+    }
+    if (two) {
+        lds_barrier();
+        a_pos = red[4];
+#pragma unroll
+        for (int u0 = 0; u0 < 64; u0 += 16) {
+            if (64 + u0 < pos) {                                    // wave-uniform; slots past pos hold +-0.0 products (weight +0.0, value 0.0): exact no-ops
+                float pb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pb[u] = prod[(u0 + u) * HS + lane];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) o = o + pb[u];
+            }
+        }
+    }
+    {
+        const float pr = a_pos * vnew;
+        o = o + pr;
+        a.out[h * HS + lane] = o;
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
+}
+
 constexpr int qa_chunk(int hs) { return (8192 / hs) & ~31; }        // V rows per LDS tile: 64 -> 128, 96 -> 64, 128 -> 64, 256 -> 32
 template <int HS> struct QaGeom { static constexpr int CH = qa_chunk(HS), NF = (CH * (HS / 4) + kBlock - 1) / kBlock; };
 
@@ -1816,7 +2067,7 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
     a.g = with_hot(a0.g, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out); a.t.st = h_st;
     const int nh = a.t.n_heads;
     if ((int)blockIdx.x < nh) {
-        if constexpr (WAVE) { if (threadIdx.x >= 64) return; }     // one wave per head: no barrier below
+        if constexpr (WAVE) { if (threadIdx.x >= (HS == 64 ? 128 : 64)) return; }     // one wave per head (two from position 64 on for 64-wide heads: attention_pair_tag)
         const uint64_t etab = exp2f_tab_lane();
         const int pos = a.t.st->pos;
         const AttTag tg{a.g.gran, *a.g.seq + 1u, a.g.att_dim, a.g.kv_dim, a.err};
@@ -1825,7 +2076,8 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
         // algorithmic bytes with head = b: profiles/r4b_traffic_llama1b_q8.json against r5_traffic_llama1b_q8.json)
         const int nkv = a.t.n_kv_heads, bq = (int)blockIdx.x / nkv, br = (int)blockIdx.x - bq * nkv;
         const int head = br * (nh / nkv) + bq;
-        if constexpr (WAVE) attention_wave_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
+        if constexpr (WAVE && HS == 64) attention_pair_tag<GEMMA>(a.t, head, pos, smem, etab, tg);
+        else if constexpr (WAVE) attention_wave_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
         else attention_body<HS, QaGeom<HS>::NF, false, false, GEMMA, false, true>(a.t, head, pos, smem, etab, AttPre(), tg);
     } else {
         gemv_static_body<N, L, PRO, EPI_QKV_TAG, kBlock, Q4>(a.g, smem, (int)blockIdx.x - nh, (int)gridDim.x - nh);
@@ -1855,7 +2107,8 @@ template <int N, int L, int PRO, bool Q4, int HS, bool GEMMA>
 static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t gsmem, int max_T, bool wave, hipStream_t s) {
     if constexpr (qa_wave_T(HS) > 0) {
         if (wave) {
-            size_t smem = WaveGeom<HS>::SMEM > gsmem ? WaveGeom<HS>::SMEM : gsmem;
+            constexpr size_t wsm = HS == 64 ? kPairSmem : WaveGeom<HS>::SMEM;
+            size_t smem = wsm > gsmem ? wsm : gsmem;
             LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a);
             return hipGetLastError();
         }

@@ -107,7 +107,7 @@ struct lmrs_ctx {
     // ---- merged qkv + attention launch (launch_qkv_attn): per-layer {value, tag} granules, the step sequence number the tags are
     // made of (bumped by the last kernel of every step, never reset), and the graph of the separate kernels for the steps it does not cover
     // qa_mode (what enqueue_layer launches): 0 the separate kernels, 1 merged with one workgroup per head (pos < qa_max_T), 2 merged with one
-    // wave per head (pos < qa_wave_T).  g_step is the graph of the best mode; g_step_alt[m] the others, captured on first use.
+    // wave per head - per 64 keys of a 64-wide head - (pos < qa_wave_T).  g_step is the graph of the best mode; g_step_alt[m] the others, captured on first use.
     bool qkv_att = false; int qa_mode = 0; unsigned long long* gran = nullptr; unsigned* seq = nullptr; int qa_max_T = 0, qa_wave_T = 0;
     hipGraphExec_t g_step_alt[3] = {nullptr, nullptr, nullptr};
     // several decode steps per graph launch (position and tokens live on the device, a step needs nothing from the host): lmrs_generate_greedy
@@ -1033,7 +1033,8 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
                      !(a.model_type == LMRS_GEMMA && !c->gemma_fused);
         c->qa_max_T = a.seq_len < 1024 ? (int)a.seq_len : 1024;
         if (c->qkv_att && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 1)) c->qa_wave_T = qkv_attn_wave_T((int)a.head_size);   // LMRS_QKV_ATT=1: workgroup form only
-        if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = 0;                  // (its prefetch reads whole 64-row blocks of the caches)
+        // (the wave forms' prefetch reads whole 64-row blocks of the caches - 128 rows for the 64-wide heads; their form for positions 128 .. 255 clamps its rows to the sequence)
+        if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = a.head_size == 64 && a.seq_len >= 128 ? (int)a.seq_len : 0;
     }
     c->no_graph = getenv("LMRS_NO_GRAPH") != nullptr;
     if (!sharded) { const int k = getenv("LMRS_STEPS_PER_GRAPH") ? atoi(getenv("LMRS_STEPS_PER_GRAPH")) : 4; c->multi_k = k < 1 ? 1 : (k > 64 ? 64 : k); }   // (measured: 4 steps per launch +1.5 % on a 20-step run, no effect on long runs)

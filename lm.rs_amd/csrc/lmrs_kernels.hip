@@ -1545,7 +1545,7 @@ template <int HS> struct WaveGeom {
     static constexpr int NPASS = TW / 64;
     static constexpr size_t SMEM = (size_t)(2 * HS + TW + 16) * 4 + (size_t)HS4 * TW * 16;
 };
-constexpr int qa_wave_T(int hs) { return hs == 64 ? 128 : ((hs == 96 || hs == 128) ? 64 : 0); }   // 0: no wave class (Gemma's 256-wide heads)
+constexpr int qa_wave_T(int hs) { return hs == 64 ? 64 * 4 : ((hs == 96 || hs == 128) ? 64 : 0); }   // 0: no wave class (Gemma's 256-wide heads)
 
 template <int HS, bool GEMMA>
 __device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
@@ -2057,6 +2057,257 @@ __device__ __forceinline__ void attention_pair_tag(const AttnArgs& a, const int 
     if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The wave form for 64-wide heads at positions 128 .. 255 (Llama-3.2-1B), with ONE WAVE PER 64 KEYS: wave w of the head's workgroup owns keys
+// 64 w .. 64 w + 63 and runs only if the context reaches them.  (Below 128 positions attention_pair_tag above runs: this form, with its keys in
+// registers instead of an LDS tile, measured 1.5 % slower per step there - profiles/r5_ab_attention_pair.txt - and 2 % faster than the workgroup
+// form from 128 on.)  A wave keeps
+// its keys AND its value rows in registers - lane l holds key 64 w + l (16 x 16-byte loads from the blocked K cache: no LDS tile) and, as an
+// output lane, v_t[l] for its 64 rows (64 buffer loads per wave: the prefetch of a 100-position context in one wave landed 2.6 us after
+// launch, later than the last qkv row) - and computes their scores and exponentials.  The reference's sequential chains cross the waves IN
+// ORDER through LDS: the maximum (order-free), the softmax sum (wave 0's 64 terms, then wave 1 continues from its partial, ...), and the value
+// chain o += a_t v_t: wave 0 adds its 64 terms while the other waves form the PRODUCTS a_t v_t of their keys (the multiplies are independent -
+// only the adds are the chain) and park them in LDS; wave 0 then adds them in key order.  Every wave polls q / k / v and rotates q for itself
+// (no hand-off before the scores); wave 0 alone writes the rotated key to the cache.  nw + 2 lds_barrier()s between the nw live waves, none
+// when there is one.  Same adds in the same order as every other form: bit-equal.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMultiWaves = 4;
+constexpr size_t kMultiSmem = (size_t)(kMultiWaves * 2 * 64 + 64 * kMultiWaves + 16 + 32) * 4 + (size_t)(kMultiWaves - 1) * 64 * 64 * 4;   // q / k per wave, weights, hand-off words, products
+template <bool GEMMA>
+__device__ __forceinline__ void attention_multi_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
+    constexpr int HS = 64, HS4 = 16, half = 32;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int nw = (pos >> 6) + 1 < kMultiWaves ? (pos >> 6) + 1 : kMultiWaves;      // live waves (uniform over the workgroup); the host keeps pos < 64 * kMultiWaves
+    if (wv >= nw) return;
+    const int tb = 64 * wv, t = tb + lane;                          // this wave's first key, this lane's key
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul, kv_dim = a.n_kv_heads * HS;
+    const int T = pos + 1, S = a.seq_len;
+    float* base = reinterpret_cast<float*>(smem);
+    float* qs = base + wv * 2 * HS;                                 // this wave's rotated query
+    float* kn = qs + HS;                                            // ... raw, then rotated key of this position
+    float* att = base + kMultiWaves * 2 * HS;                       // 64 * kMultiWaves + 16 weights (shared)
+    float* red = att + 64 * kMultiWaves + 16;                       // hand-off words: [0..3] maxima, [4] a_pos, [8..11] running sums
+    float* prod = red + 32;                                         // [keys of waves 1..][HS]: a_t * v_t
+    float* kT = att_k_head(a, kvh, HS);
+    const float* vbase = a.v_cache + (size_t)a.layer * S * kv_dim + kvh * HS;
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[0] = wall_clock64();
+
+    const float2 cs = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + (lane < half ? lane : 0)) * 2);
+    // this lane's key: dims 4g .. 4g+3 at ((g * S + t) * 4) of the blocked cache - 16 bytes per lane, a wave reads 1 KiB per load (lanes past the
+    // sequence clamp to its last row: their scores are replaced below; the new key's lane is patched after the RoPE step)
+    f32x4v kreg[HS4];
+    {
+        const int tk = t < S ? t : S - 1;
+        if (tb < pos) {                                             // wave-uniform
+#pragma unroll
+            for (int g = 0; g < HS4; ++g) kreg[g] = *reinterpret_cast<const f32x4v*>(kT + ((size_t)g * S + tk) * 4);
+        } else {
+#pragma unroll
+            for (int g = 0; g < HS4; ++g) kreg[g] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    // this wave's value rows: v[u] = v_{tb + u}[lane], blocks of 16 rows nested so that the prefetch has one join (see attention_wave_tag)
+    float v[64];
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vbase), 0, 0x7fffffff, 0x00020000);
+    const int vrow = kv_dim * 4;
+    auto vblock = [&](auto self, auto u0c) __attribute__((always_inline)) -> void {
+        constexpr int u0 = decltype(u0c)::value;
+        if constexpr (u0 < 64) {
+            if (tb + u0 < pos) {                                    // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int row = tb + u0 + u < S ? tb + u0 + u : S - 1;                       // (scalar: rows past the sequence re-read its last row, their weight is +0.0)
+                    v[u0 + u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vrs, lane * 4, row * vrow, 0));
+                }
+                self(self, std::integral_constant<int, u0 + 16>());
+            }
+        }
+    };
+    vblock(vblock, std::integral_constant<int, 0>());
+#pragma unroll
+    for (int u = 0; u < 64; ++u) { v[u] = tb + u < pos ? v[u] : 0.0f; asm volatile("" : "+v"(v[u])); }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[1] = wall_clock64();
+
+    // ---- q, raw k, v of this position: poll the granules (every wave: no hand-off before the scores)
+    unsigned long long xg[3];
+    {
+        const unsigned long long* gp[3] = {tg.gran + h * HS + lane, tg.gran + tg.att_dim + kvh * HS + lane, tg.gran + tg.att_dim + tg.kv_dim + kvh * HS + lane};
+        auto sweep = [&](unsigned long long (&x)[3]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[k] = __hip_atomic_load(gp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto fresh = [&](const unsigned long long (&x)[3]) __attribute__((always_inline)) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ok = ok && (unsigned)(x[k] >> 32) == tg.tag;
+            return __all(ok) != 0;
+        };
+        unsigned long long xa[3], xb[3];
+        sweep(xa);
+        for (unsigned spins = 0;; ++spins) {
+            sweep(xb);
+            if (fresh(xa)) { xg[0] = xa[0]; xg[1] = xa[1]; xg[2] = xa[2]; break; }
+            sweep(xa);
+            if (fresh(xb)) { xg[0] = xb[0]; xg[1] = xb[1]; xg[2] = xb[2]; break; }
+            if (spins > kTagSpinMax || (spins & 1023) == 1023) {     // bounded: report and finish with garbage instead of hanging
+                const int e = __hip_atomic_load(tg.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e != 0 || spins > kTagSpinMax) {
+                    if (e == 0) __hip_atomic_store(tg.err, a.layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xg[0] = xb[0]; xg[1] = xb[1]; xg[2] = xb[2];
+                    break;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[2] = wall_clock64();
+    const float vnew = __uint_as_float((unsigned)xg[2]);
+    qs[lane] = __uint_as_float((unsigned)xg[0]); kn[lane] = __uint_as_float((unsigned)xg[1]);
+    // RoPE (transformer.rs:480-491): lane j < 32 owns pair (j, j + 32); wave 0 stores the rotated key into the cache, the wave that owns
+    // position `pos` patches it into that key's lane
+    const bool own_pos = (pos >> 6) == wv;
+    if (lane < half) {
+        const int j = lane;
+        const float fcr = cs.x, fci = cs.y;
+        {
+            const float v0 = qs[j], v1 = qs[j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            qs[j] = a0 - a1; qs[j + half] = b0 + b1;
+        }
+        const float v0 = kn[j], v1 = kn[j + half];
+        const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+        const float r0 = a0 - a1, r1 = b0 + b1;
+        kn[j] = r0; kn[j + half] = r1;
+        if (wv == 0) {
+            kT[(((size_t)(j >> 2) * S + pos) << 2) + (j & 3)] = r0;
+            kT[(((size_t)((j + half) >> 2) * S + pos) << 2) + ((j + half) & 3)] = r1;
+        }
+    }
+    if (own_pos) {                                                  // wave-uniform
+#pragma unroll
+        for (int g = 0; g < HS4; ++g) {
+            const float4 n4 = reinterpret_cast<const float4*>(kn)[g];
+            const bool me = lane == (pos & 63);
+            kreg[g][0] = me ? n4.x : kreg[g][0]; kreg[g][1] = me ? n4.y : kreg[g][1]; kreg[g][2] = me ? n4.z : kreg[g][2]; kreg[g][3] = me ? n4.w : kreg[g][3];
+        }
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[3] = wall_clock64();
+
+    // ---- scores (transformer.rs:507-529): one lane per key of this wave, sequential dot over the head dims
+    int wpos = pos;
+    if constexpr (GEMMA) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
+    const float sqrt_hs = sqrtf((float)HS), ninf = __uint_as_float(0xff800000u);
+    float sc;
+    {
+        float score = 0.0f;
+#pragma unroll
+        for (int g = 0; g < HS4; ++g) {
+            const float4 q4 = reinterpret_cast<const float4*>(qs)[g];
+            float pr;
+            pr = q4.x * kreg[g][0]; score = score + pr;
+            pr = q4.y * kreg[g][1]; score = score + pr;
+            pr = q4.z * kreg[g][2]; score = score + pr;
+            pr = q4.w * kreg[g][3]; score = score + pr;
+        }
+        score = score / sqrt_hs;
+        if constexpr (GEMMA) {                                      // transformer.rs:518-526
+            score = score / 50.0f;
+            score = (float)tanh((double)score);
+            score = score * 50.0f;
+            score = score + (((unsigned)(wpos - t) <= 4096u) ? 0.0f : -2.3819763e38f);
+        }
+        sc = t < T ? score : ninf;
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[4] = wall_clock64();
+    // ---- softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide
+    float mx = wave64_max(sc);
+    if (nw > 1) {
+        if (lane == 0) red[wv] = mx;
+        lds_barrier();
+        mx = red[0];
+        for (int w = 1; w < nw; ++w) mx = fmaxf(mx, red[w]);
+    }
+    const float e0 = expf_glibc_t(t < T ? sc - mx : 0.0f, etab);
+    const float ex = t < T ? e0 : 0.0f;                             // the lanes past T hold +0.0 (exact: the running sum is >= +0)
+    float sum;
+    if (nw == 1) {
+        sum = wave_serial_sum(0.0f, ex, (T + 15) >> 4);
+    } else {
+        for (int s = 0; s < nw; ++s) {                              // the chain, wave after wave
+            if (wv == s) {
+                const int left = T - 64 * s;
+                const float part = wave_serial_sum(s ? red[8 + s - 1] : 0.0f, ex, left >= 64 ? 4 : (left + 15) >> 4);
+                if (lane == 0) red[8 + s] = part;
+            }
+            lds_barrier();
+        }
+        sum = red[8 + nw - 1];
+    }
+    const float w = ex / sum;
+    att[t] = t < pos ? w : 0.0f;                                    // the chains below cover the earlier positions; this one follows from registers
+    float a_pos = 0.0f;
+    if (own_pos) a_pos = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), pos & 63));
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[5] = wall_clock64();
+    // ---- weighted sum of values (transformer.rs:533-541), t ascending; lane = output dim
+    if (wv > 0) {                                                   // the products of this wave's keys, for wave 0 to add in order
+        if (own_pos && lane == 0) red[4] = a_pos;
+        float* mine = prod + (size_t)(wv - 1) * 64 * HS;
+#pragma unroll
+        for (int u0 = 0; u0 < 64; u0 += 16) {
+            if (tb + u0 < pos) {                                    // wave-uniform
+                float4 w4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w4[u] = reinterpret_cast<const float4*>(att)[(tb + u0) / 4 + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mine[(u0 + 4 * u + 0) * HS + lane] = w4[u].x * v[u0 + 4 * u + 0];
+                    mine[(u0 + 4 * u + 1) * HS + lane] = w4[u].y * v[u0 + 4 * u + 1];
+                    mine[(u0 + 4 * u + 2) * HS + lane] = w4[u].z * v[u0 + 4 * u + 2];
+                    mine[(u0 + 4 * u + 3) * HS + lane] = w4[u].w * v[u0 + 4 * u + 3];
+                }
+            }
+        }
+        lds_barrier();
+        return;
+    }
+    float o = 0.0f;
+#pragma unroll
+    for (int u0 = 0; u0 < 64; u0 += 16) {
+        if (u0 < pos) {                                             // wave-uniform
+            float4 w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w4[u] = reinterpret_cast<const float4*>(att)[u0 / 4 + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float pr;
+                pr = w4[u].x * v[u0 + 4 * u + 0]; o = o + pr;
+                pr = w4[u].y * v[u0 + 4 * u + 1]; o = o + pr;
+                pr = w4[u].z * v[u0 + 4 * u + 2]; o = o + pr;
+                pr = w4[u].w * v[u0 + 4 * u + 3]; o = o + pr;
+            }
+        }
+    }
+    if (nw > 1) {
+        lds_barrier();
+        a_pos = red[4];
+        for (int k0 = 0; k0 < 64 * (kMultiWaves - 1); k0 += 16) {
+            if (64 + k0 < pos) {                                    // wave-uniform; slots past pos hold +-0.0 products (weight +0.0, value 0.0): exact no-ops
+                float pb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pb[u] = prod[(k0 + u) * HS + lane];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) o = o + pb[u];
+            }
+        }
+    }
+    {
+        const float pr = a_pos * vnew;
+        o = o + pr;
+        a.out[h * HS + lane] = o;
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
+}
+
 constexpr int qa_chunk(int hs) { return (8192 / hs) & ~31; }        // V rows per LDS tile: 64 -> 128, 96 -> 64, 128 -> 64, 256 -> 32
 template <int HS> struct QaGeom { static constexpr int CH = qa_chunk(HS), NF = (CH * (HS / 4) + kBlock - 1) / kBlock; };
 
@@ -2067,7 +2318,7 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
     a.g = with_hot(a0.g, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out); a.t.st = h_st;
     const int nh = a.t.n_heads;
     if ((int)blockIdx.x < nh) {
-        if constexpr (WAVE) { if (threadIdx.x >= (HS == 64 ? 128 : 64)) return; }     // one wave per head (two from position 64 on for 64-wide heads: attention_pair_tag)
+        if constexpr (WAVE) { if (HS != 64 && threadIdx.x >= 64) return; }     // one wave per head (64-wide heads: one wave per 64 keys, attention_multi_tag)
         const uint64_t etab = exp2f_tab_lane();
         const int pos = a.t.st->pos;
         const AttTag tg{a.g.gran, *a.g.seq + 1u, a.g.att_dim, a.g.kv_dim, a.err};
@@ -2076,7 +2327,7 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
         // algorithmic bytes with head = b: profiles/r4b_traffic_llama1b_q8.json against r5_traffic_llama1b_q8.json)
         const int nkv = a.t.n_kv_heads, bq = (int)blockIdx.x / nkv, br = (int)blockIdx.x - bq * nkv;
         const int head = br * (nh / nkv) + bq;
-        if constexpr (WAVE && HS == 64) attention_pair_tag<GEMMA>(a.t, head, pos, smem, etab, tg);
+        if constexpr (WAVE && HS == 64) { if (pos < 128) attention_pair_tag<GEMMA>(a.t, head, pos, smem, etab, tg); else attention_multi_tag<GEMMA>(a.t, head, pos, smem, etab, tg); }
         else if constexpr (WAVE) attention_wave_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
         else attention_body<HS, QaGeom<HS>::NF, false, false, GEMMA, false, true>(a.t, head, pos, smem, etab, AttPre(), tg);
     } else {
@@ -2107,7 +2358,7 @@ template <int N, int L, int PRO, bool Q4, int HS, bool GEMMA>
 static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t gsmem, int max_T, bool wave, hipStream_t s) {
     if constexpr (qa_wave_T(HS) > 0) {
         if (wave) {
-            constexpr size_t wsm = HS == 64 ? kPairSmem : WaveGeom<HS>::SMEM;
+            constexpr size_t wsm = HS == 64 ? (kMultiSmem > kPairSmem ? kMultiSmem : kPairSmem) : WaveGeom<HS>::SMEM;
             size_t smem = wsm > gsmem ? wsm : gsmem;
             LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a);
             return hipGetLastError();

@@ -79,6 +79,7 @@ struct lmrs_ctx {
     // batched prefill on row shards (plan "tp", Q8_0): the gathered blocks of a token batch - per shard [n_tok x slice int8 | n_tok x slice / 128 scales],
     // pfb_att / pfb_h bytes apart; inside the peer-to-peer arena when that is the transport (peers write them), ordinary memory for RCCL
     char *pfx_att = nullptr, *pfx_h = nullptr; size_t pfb_att = 0, pfb_h = 0; bool pfx_owned = false;
+    bool tp_prefill = false;                               // decided ONCE, at create (prefill_tp_shapes_ok: shapes and LMRS_NO_BATCHED_PREFILL) - where the blocks live follows from it
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool no_graph = false;                         // LMRS_NO_GRAPH=1 (read at create): steps are enqueued launch by launch (profiling aid, see launch_step)
@@ -889,6 +890,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4); need(W * 2 * kMaxArgmaxParts * 4);
     // quantised exchange payloads (Q8_0, whole 128-groups per shard): one padded block per shard
     c->qpay = sharded && !cls_only && !c->q4 && att_l % 128 == 0 && hid_l % 128 == 0 && !getenv("LMRS_SHARD_F32_PAYLOAD");
+    c->tp_prefill = prefill_tp_shapes_ok(c);
     c->blk_att = pad256(att_l + att_l / 32); c->blk_h = pad256(hid_l + hid_l / 32);
     need(W * c->blk_att); need(W * c->blk_h);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
@@ -965,7 +967,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         auto xneed = [&](size_t b) { const size_t o = xo; xo += pad256(b); return o; };
         const size_t o_att = xneed(att * 4), o_h = xneed(hid * 4), o_tmp = xneed(dim * 4), o_logits = xneed(V * 4), o_part = xneed(2 * W * 2 * kMaxArgmaxParts * 4),
                      o_gqa = xneed(W * c->blk_att), o_gqh = xneed(W * c->blk_h), o_flags = xneed((size_t)kMaxExchangeSlots * kMaxWorld * 4), o_seq = xneed((size_t)kMaxExchangeSlots * 4), o_err = xneed(256);
-        const bool tpb = prefill_tp_shapes_ok(c);             // token-batch blocks of the batched prefill (two buffers: see prefill_layers_tp)
+        const bool tpb = c->tp_prefill;                       // token-batch blocks of the batched prefill (two buffers: see prefill_layers_tp)
         c->pfb_att = prefill_tp_block(att_l); c->pfb_h = prefill_tp_block(hid_l);
         const size_t o_pfa = tpb ? xneed(W * c->pfb_att) : 0, o_pfh = tpb ? xneed(W * c->pfb_h) : 0;
         HCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->xarena), xo, hipDeviceMallocFinegrained));
@@ -1261,7 +1263,7 @@ static int prefill_alloc(lmrs_ctx* c) {
     if (c->pf_ready) return 0;
     const lmrs_args& a = c->args;
     const size_t B = kPrefillTokens, wide = std::max<size_t>(std::max<size_t>(a.dim, a.hidden_dim), (size_t)std::max(c->att_dim, c->att_full));
-    const bool own_blocks = (c->world > 1 || c->comm) && !c->cls_only && !c->pfx_att;        // (peer-to-peer shards: the blocks are part of the exchange arena)
+    const bool own_blocks = c->tp_prefill && c->comm && !c->pfx_att;      // (peer-to-peer shards: the blocks are part of the exchange arena, laid out at create)
     if (own_blocks) { c->pfb_att = prefill_tp_block((size_t)c->att_dim); c->pfb_h = prefill_tp_block((size_t)c->hid_l); c->pfx_owned = true; }
     struct Want { void** p; size_t bytes; } want[] = {
         {reinterpret_cast<void**>(&c->pf_x), B * a.dim * 4}, {reinterpret_cast<void**>(&c->pf_q), B * c->att_dim * 4},
@@ -1395,7 +1397,7 @@ static int prefill_layers_tp(lmrs_ctx* c, int m, int p0) {
 }
 // (a communicator of ONE rank counts as a row-sharded context - the RCCL branch of the batched path can then run, and be tested, on a one-GPU box)
 static bool row_sharded(const lmrs_ctx* c) { return (c->world > 1 || c->comm) && !c->cls_only; }
-static bool prefill_tp_ok(const lmrs_ctx* c) { return row_sharded(c) && (c->comm || (c->p2p && c->p2p_ready)) && prefill_tp_shapes_ok(c); }
+static bool prefill_tp_ok(const lmrs_ctx* c) { return c->tp_prefill && row_sharded(c) && (c->comm || (c->p2p && c->p2p_ready && c->pfx_att)); }
 static int prefill_pass(lmrs_ctx* c, int m, int p0) {
     if (row_sharded(c)) { c->ex_slot = 0; return prefill_layers_tp(c, m, p0); }
     return prefill_layers(c, m, p0);

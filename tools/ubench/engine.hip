@@ -16,7 +16,7 @@
 //   * self-check: x after 16 layers against a host loop of the same arithmetic, bit for bit, for CHECK positions.
 // Output: us per step / per layer and a stamp table (gather / prologue / rows / attention per stage) of an attention CU and a plain one.
 //
-// Build: make -C tools/ubench engine.   Run: tools/ubench/engine [steps] [thin=1|0] [depth]
+// Build: make -C tools/ubench engine.   Run: tools/ubench/engine [steps] [thin=1|0] [depth 2..6] [debug=0|1] [consumer waves 3|7]
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -35,7 +35,7 @@ constexpr int TW = 32;                                                          
 constexpr int NATT = NH / 2;                                                                     // attention CUs (two heads each)
 constexpr float EPS = 1e-5f;
 constexpr unsigned SPIN_MAX = 1u << 21;
-constexpr int NST = 16;                                                                          // stamps per (layer, wave)
+constexpr int NST = 16, NSTX = 96;                                                               // stamps per (layer, wave): 16 stage stamps + 9 jobs x 8
 
 struct EArgs {
     const char* stream; const float* norms; const float2* rope; float* kc; float* vc; const float* x_in; float* x_out;
@@ -45,7 +45,7 @@ struct EArgs {
 __host__ __device__ constexpr unsigned tag_of(unsigned base, int layer, int edge) { return base + (unsigned)layer * 8u + (unsigned)edge + 1u; }
 
 // ---------------------------------------------------------------------------------------------------------------- LDS map
-struct Ctl { unsigned full[16], freeq[16], bar, gath, pairbar, pad; float pairmax[2]; float hloc[32]; };
+struct Ctl { unsigned full[16], freeq[16], bar, gath, pairbar, issued; float pairmax[2]; float ss, pad; float hraw[64]; };
 constexpr int JP = 328;                                            // row pitch of the RMS squares (8 rows; skewed: see prologue)
 constexpr size_t OFF_RING = 0, OFF_XQ = OFF_RING + (size_t)RING * SLOTB, OFF_XS = OFF_XQ + HID, OFF_XF = OFF_XS + 256, OFF_SQ = OFF_XF + D * 4,
                  OFF_ATT = OFF_SQ + 8 * JP * 4 + 64, OFF_CTL = OFF_ATT + 2 * 1024, SMEM = OFF_CTL + sizeof(Ctl);
@@ -88,6 +88,7 @@ __device__ __forceinline__ void loader(const EArgs& a, char* smem, Ctl* ctl, int
             __builtin_amdgcn_global_load_lds((const LMRS_GLOBAL void*)(g + u * 1024 + lane * 16), (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, 0, 2);
         __builtin_amdgcn_global_load_lds((const LMRS_GLOBAL void*)(g + 8192 + lane * 4), (__attribute__((address_space(3))) void*)(dst + 8192), 4, 0, 2);
         // slots in flight behind this one: depth - 1 normally, ONE while this CU gathers (its sweeps queue behind the loader's requests)
+        if (lane == 0) lds_st(&ctl->issued, (unsigned)(s + 1));
         const bool thin = a.thin && lds_ld(&ctl->gath) != 0;
         int keep;
         if (thin || a.depth <= 2) { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); keep = 1; }
@@ -111,9 +112,11 @@ template <int L> __device__ __forceinline__ void load_act(Act& A, const char* sm
     for (int u = 0; u < 8; ++u) { A.xa[u] = *reinterpret_cast<const i32x4*>(xq + (cl * 8 + u) * 128 + rc * 16); A.xs[u] = xs[cl * 8 + u]; }
 }
 // one job = one ring slot: -> the rows' sums (functional.rs:173-214: groups ascending), valid in the last cluster of every row of L lanes
-template <int L> __device__ __forceinline__ float run_job(const EArgs& a, char* smem, Ctl* ctl, int s, const Act& A, int lane) {
+template <int L> __device__ __forceinline__ float run_job(const EArgs& a, char* smem, Ctl* ctl, int s, const Act& A, int lane, long long* js = nullptr) {
     const int ring = s % RING; const unsigned round = (unsigned)(s / RING);
+    if (js) { js[0] = wall_clock64(); js[4] = (long long)lds_ld(&ctl->issued) - s; }
     lds_wait_ge(&ctl->full[ring], round + 1u, a.err, 200);
+    if (js) js[1] = wall_clock64();
     const char* slot = smem + OFF_RING + (size_t)ring * SLOTB;
     i32x4 w[8]; float sc[8];
 #pragma unroll
@@ -134,6 +137,7 @@ template <int L> __device__ __forceinline__ float run_job(const EArgs& a, char* 
         pb[u] = p * A.xs[u];
         if (u == 7) { lds_drain(); if (lane == 0) lds_st(&ctl->freeq[ring], round + 1u); }          // the slot is in registers: hand it back
     }
+    if (js) js[2] = wall_clock64();
     constexpr int NC = L / 8;
     const int cl = (lane % L) / 8;
     float acc = 0.0f;
@@ -147,11 +151,12 @@ template <int L> __device__ __forceinline__ float run_job(const EArgs& a, char* 
             for (int u = 0; u < 8; ++u) acc = acc + pb[u];
         }
     }
+    if (js) js[3] = wall_clock64();
     return acc;
 }
-__device__ __forceinline__ void cbar(Ctl* ctl, unsigned& phase, int* err, int lane) {                // the three consumer waves
+template <int NCW> __device__ __forceinline__ void cbar(Ctl* ctl, unsigned& phase, int* err, int lane) {  // the NCW consumer waves
     lds_drain();
-    phase += 3;
+    phase += NCW;
     if (lane == 0) __hip_atomic_fetch_add(&ctl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     lds_wait_ge(&ctl->bar, phase, err, 300);
 }
@@ -191,43 +196,28 @@ __device__ __forceinline__ unsigned pack_quad(int q, int lane) {                
     return (unsigned)v;
 }
 
-// RMSNorm + quantise of the 2048 floats in LDS (xf) by ONE wave -> xq / xs.  functional.rs:48-78, quantization.rs:44-67.
-// Lane t owns the quarter group (t / 4) * 128 + 16 i + 4 (t % 4) .. + 3, i < 8: one maximum over 4 lanes, one scale per lane.
-__device__ __forceinline__ void prologue(char* smem, const float4 (&nw)[8], int lane) {
-    const float* xf = reinterpret_cast<const float*>(smem + OFF_XF); float* sq = reinterpret_cast<float*>(smem + OFF_SQ);
-    int8_t* xq = reinterpret_cast<int8_t*>(smem + OFF_XQ); float* xs = reinterpret_cast<float*>(smem + OFF_XS);
-    const int t = lane, e0 = (t >> 2) * 128 + (t & 3) * 4;
-    float4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(xf + e0 + 16 * i);
-    // squares: chain k = e & 7 takes x[8 j + k] in ascending j; row k of sq, position j + 4 (j >> 4) (the skew spreads the 16-value blocks of
-    // consecutive lane quads over the banks: 2-way conflicts instead of 8-way)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k0 = (t & 1) * 4, j = (t >> 2) * 16 + 2 * i + ((t & 3) >> 1), at = j + 4 * (t >> 2);
-        sq[(k0 + 0) * JP + at] = v[i].x * v[i].x; sq[(k0 + 1) * JP + at] = v[i].y * v[i].y;
-        sq[(k0 + 2) * JP + at] = v[i].z * v[i].z; sq[(k0 + 3) * JP + at] = v[i].w * v[i].w;
-    }
-    lds_drain();
+// RMSNorm of the 2048 floats in LDS (functional.rs:48-78).  The gathering waves leave the squares in `sq` beside the values: chain k = e & 7
+// takes x[8 j + k] in ascending j; row k of sq, position j + 4 (j >> 4) (the skew spreads consecutive 16-value blocks over the banks).
+__device__ __forceinline__ int sq_at(int e) { const int j = e >> 3; return (e & 7) * JP + j + 4 * (j >> 4); }
+__device__ __forceinline__ float rms_chain(char* smem, int lane) {                                   // one wave -> 1 / sqrt(mean square + eps), in every lane
+    const float* sq = reinterpret_cast<const float*>(smem + OFF_SQ);
     float p = 0.0f;
-    {
-        const int cl = t & 15;
-        const float* row = sq + (cl & 7) * JP + 4 * (cl >> 3);
-        float4 A[4], B[4];
-        auto rd = [&](float4 (&X)[4], int m0) __attribute__((always_inline)) {
+    const int cl = lane & 15;
+    const float* row = sq + (cl & 7) * JP + 4 * (cl >> 3);
+    float4 A[4], B[4];
+    auto rd = [&](float4 (&X)[4], int m0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int m = m0 + u; X[u] = *reinterpret_cast<const float4*>(row + 8 * m + 4 * (m >> 1)); }
-        };
-        rd(A, 0);
+        for (int u = 0; u < 4; ++u) { const int m = m0 + u; X[u] = *reinterpret_cast<const float4*>(row + 8 * m + 4 * (m >> 1)); }
+    };
+    rd(A, 0);
 #pragma unroll
-        for (int m0 = 0; m0 < D / 64; m0 += 8) {                      // a chain is D / 8 values = D / 64 steps of (4 own + 4 of the lane 8 above)
-            rd(B, m0 + 4);
-            asm volatile("" ::: "memory");
-            rms_chain32(p, A);
-            if (m0 + 8 < D / 64) rd(A, m0 + 8);
-            asm volatile("" ::: "memory");
-            rms_chain32(p, B);
-        }
+    for (int m0 = 0; m0 < D / 64; m0 += 8) {                          // a chain is D / 8 values = D / 64 steps of (4 own + 4 of the lane 8 above)
+        rd(B, m0 + 4);
+        asm volatile("" ::: "memory");
+        rms_chain32(p, A);
+        if (m0 + 8 < D / 64) rd(A, m0 + 8);
+        asm volatile("" ::: "memory");
+        rms_chain32(p, B);
     }
     const int pi = __float_as_int(p);
     const float p0 = __int_as_float(__builtin_amdgcn_readlane(pi, 0)), p1 = __int_as_float(__builtin_amdgcn_readlane(pi, 1));
@@ -236,19 +226,29 @@ __device__ __forceinline__ void prologue(char* smem, const float4 (&nw)[8], int 
     const float p6 = __int_as_float(__builtin_amdgcn_readlane(pi, 6)), p7 = __int_as_float(__builtin_amdgcn_readlane(pi, 7));
     float ss = reduce_add8(p0, p1, p2, p3, p4, p5, p6, p7);
     ss = ss * (1.0f / (float)D); ss = ss + EPS; ss = 1.0f / sqrtf(ss);
-    if (t == 0) { sq[8 * JP] = ss; for (int k = 0; k < 8; ++k) sq[8 * JP + 1 + k] = __int_as_float(__builtin_amdgcn_readlane(pi, k)); }
+    return ss;
+}
+// normalise + quantise (quantization.rs:44-67) by NQ waves: wave wq owns 16 / NQ groups, 4 NQ lanes per group, 8 / NQ float4 per lane
+template <int NQ> struct QGeom { static constexpr int LG = 4 * NQ, NF = 8 / NQ;
+    __device__ static __forceinline__ int elem(int wq, int lane, int i) { return (wq * (16 / NQ) + lane / LG) * 128 + (lane % LG) * 4 + LG * 4 * i; } };
+template <int NQ> __device__ __forceinline__ void norm_quant(char* smem, int wq, const float4 (&nw)[(QGeom<NQ>::NF)], float ss, int lane) {
+    using Q = QGeom<NQ>;
+    const float* xf = reinterpret_cast<const float*>(smem + OFF_XF);
+    int8_t* xq = reinterpret_cast<int8_t*>(smem + OFF_XQ); float* xs = reinterpret_cast<float*>(smem + OFF_XS);
+    float4 v[Q::NF];
     float mg = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < Q::NF; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(xf + Q::elem(wq, lane, i));
         v[i].x = nw[i].x * (ss * v[i].x); v[i].y = nw[i].y * (ss * v[i].y); v[i].z = nw[i].z * (ss * v[i].z); v[i].w = nw[i].w * (ss * v[i].w);
         mg = absmax4(v[i], mg);
     }
-    mg = cluster_max<4>(mg);
+    mg = cluster_max<Q::LG>(mg);
     const bool sane = quant_group_sane(mg);
     float mm = mg; asm volatile("" : "+v"(mm));
     const float sc = sane ? div127_sane(mg) : mm / 127.0f, inv = __builtin_amdgcn_rcpf(sc);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < Q::NF; ++i) {
         float4 d; int q[4];
         q[0] = quant_q8_cand(v[i].x, inv, d.x); q[1] = quant_q8_cand(v[i].y, inv, d.y); q[2] = quant_q8_cand(v[i].z, inv, d.z); q[3] = quant_q8_cand(v[i].w, inv, d.w);
         if (__any(!sane || absmax4(d, 0.0f) > kQuantDevMax)) {
@@ -257,9 +257,9 @@ __device__ __forceinline__ void prologue(char* smem, const float4 (&nw)[8], int 
             if (!sane || fabsf(d.z) > kQuantDevMax) q[2] = quant_q8(v[i].z, sc);
             if (!sane || fabsf(d.w) > kQuantDevMax) q[3] = quant_q8(v[i].w, sc);
         }
-        *reinterpret_cast<unsigned*>(xq + e0 + 16 * i) = (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
+        *reinterpret_cast<unsigned*>(xq + Q::elem(wq, lane, i)) = (unsigned)(q[0] & 0xff) | ((unsigned)(q[1] & 0xff) << 8) | ((unsigned)(q[2] & 0xff) << 16) | ((unsigned)(q[3] & 0xff) << 24);
     }
-    if ((t & 3) == 0) xs[t >> 2] = sc;
+    if ((lane % Q::LG) == 0) xs[wq * (16 / NQ) + lane / Q::LG] = sc;
 }
 
 // one head of one attention CU (transformer.rs:443-544): RoPE, K / V row of this position, scores, softmax, weighted values, then the pair's
@@ -368,55 +368,59 @@ __device__ __forceinline__ void attention(const EArgs& a, char* smem, Ctl* ctl, 
     // (second use of pairmax in the next layer is ordered behind this one by the layer's all-to-all edges)
 }
 
-__device__ __forceinline__ void consumer(const EArgs& a, char* smem, Ctl* ctl, int cu, int cw, int lane) {
-    float* xf = reinterpret_cast<float*>(smem + OFF_XF);
+template <int NCW> __device__ __forceinline__ void consumer(const EArgs& a, char* smem, Ctl* ctl, int cu, int cw, int lane) {
+    constexpr int NGW = NCW >= 4 ? 4 : 2, NGX = 2048 / NGW / 64;           // waves that sweep x, granules per lane
+    constexpr int NQ = NCW >= 4 ? 4 : 1;                                   // waves that normalise + quantise
+    constexpr int ATT0 = NCW >= 5 ? 3 : 0;                                 // the attention CUs' two head waves (7 consumers: waves without a qkv job)
+    constexpr int AGW = NCW >= 6 ? 5 : 0;                                  // the wave that gathers att_out
+    constexpr int NHW = NCW >= 6 ? 6 : 3, HCNT = 2112 / NHW, NGH = (HCNT + 63) / 64;   // waves that sweep h, granules per wave / per lane
+    float* xf = reinterpret_cast<float*>(smem + OFF_XF); float* sq = reinterpret_cast<float*>(smem + OFF_SQ);
     unsigned* xqw = reinterpret_cast<unsigned*>(smem + OFF_XQ); float* xs = reinterpret_cast<float*>(smem + OFF_XS);
     unsigned phase = 0, pairphase = 0;
-    const bool stamped = a.stamps && (cu == 0 || cu == 200) && lane == 0;
+    const bool stamped = a.stamps && (cu == 0 || cu == 200) && lane == 0 && cw == 0;
+    const uint64_t etab = exp2f_tab_lane();
     if (cw == 0 && lane < 8) put_gran(a.xg, cu * 8 + lane, __float_as_uint(a.x_in[cu * 8 + lane]), tag_of(a.base, 0, 0));
     Act A;
     for (int layer = 0; layer < a.nl; ++layer) {
-        long long* st = stamped ? a.stamps + (((size_t)(cu == 0 ? 0 : 1) * NL + layer) * 3 + cw) * NST : nullptr;
+        long long* st = stamped ? a.stamps + ((size_t)(cu == 0 ? 0 : 1) * NL + layer) * NSTX : nullptr;
         const int s0 = layer * SLOTS;
         auto gather_x = [&](int edge, const float* nwp) __attribute__((always_inline)) {
-            float4 nw[8];
-            if (cw == 0) {
+            float4 nw[QGeom<NQ>::NF];
+            if (cw < NQ) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) nw[i] = *reinterpret_cast<const float4*>(nwp + (lane >> 2) * 128 + (lane & 3) * 4 + 16 * i);
+                for (int i = 0; i < QGeom<NQ>::NF; ++i) nw[i] = *reinterpret_cast<const float4*>(nwp + QGeom<NQ>::elem(cw, lane, i));
             }
-            if (cw < 2) {
-                unsigned val[16];
+            if (cw < NGW) {
+                unsigned val[NGX];
                 gath_mark(ctl, lane, 1);
-                sweep<16>(a.xg, cw * 1024, 1024, tag_of(a.base, layer, edge), val, a.err, 600 + edge, lane);
+                sweep<NGX>(a.xg, cw * (2048 / NGW), 2048 / NGW, tag_of(a.base, layer, edge), val, a.err, 600 + edge, lane);
                 gath_mark(ctl, lane, -1);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) xf[cw * 1024 + 64 * k + lane] = __uint_as_float(val[k]);
+                for (int k = 0; k < NGX; ++k) { const int e = cw * (2048 / NGW) + 64 * k + lane; const float v = __uint_as_float(val[k]); xf[e] = v; sq[sq_at(e)] = v * v; }
             }
             if (st) st[edge == 0 ? 0 : 8] = wall_clock64();
-            cbar(ctl, phase, a.err, lane);
-            if (cw == 0) prologue(smem, nw, lane);
-            if (a.dbg && cu == 0 && cw == 0 && layer == 0 && edge == 0) {
-                lds_drain();
-                for (int i = lane; i < D; i += 64) a.dbg[i] = xf[i];
-                for (int i = lane; i < 512; i += 64) a.dbg[D + i] = __uint_as_float(xqw[i]);
-                if (lane < 16) a.dbg[D + 512 + lane] = xs[lane];
-                if (lane < 9) a.dbg[D + 528 + lane] = reinterpret_cast<const float*>(smem + OFF_SQ)[8 * JP + lane];
-            }
-            cbar(ctl, phase, a.err, lane);
+            cbar<NCW>(ctl, phase, a.err, lane);
+            if (cw == 0) { const float ss = rms_chain(smem, lane); if (lane == 0) ctl->ss = ss; }
+            if (st) st[edge == 0 ? 14 : 15] = wall_clock64();
+            cbar<NCW>(ctl, phase, a.err, lane);
+            if (cw < NQ) norm_quant<NQ>(smem, cw, nw, *(volatile float*)&ctl->ss, lane);
+            if (a.dbg && cu == 0 && cw == 0 && layer == 0 && edge == 0) { lds_drain(); for (int i = lane; i < D; i += 64) a.dbg[i] = xf[i]; a.dbg[D + 528] = ctl->ss; }
+            cbar<NCW>(ctl, phase, a.err, lane);
+            if (a.dbg && cu == 0 && cw == 0 && layer == 0 && edge == 0) { for (int i = lane; i < 512; i += 64) a.dbg[D + i] = __uint_as_float(xqw[i]); if (lane < 16) a.dbg[D + 512 + lane] = xs[lane]; }
             if (st) st[edge == 0 ? 1 : 9] = wall_clock64();
         };
         // ---- x -> RMSNorm -> quantise -> q, k, v rows
         gather_x(0, a.norms + (size_t)layer * 2 * D);
-        load_act<16>(A, smem, lane);
-        {
+        if (cw < JQ) {
+            load_act<16>(A, smem, lane);
             const float r = run_job<16>(a, smem, ctl, s0 + cw, A, lane);
             if ((lane & 15) == 8) put_gran(a.qkvg, cu * 12 + cw * 4 + (lane >> 4), __float_as_uint(r), tag_of(a.base, layer, 1));
         }
         if (st) st[2] = wall_clock64();
-        if (cu < NATT && cw < 2) attention(a, smem, ctl, layer, cu, cw, lane, pairphase, st);
+        if (cu < NATT && cw >= ATT0 && cw < ATT0 + 2) attention(a, smem, ctl, layer, cu, cw - ATT0, lane, pairphase, (a.stamps && cu == 0 && lane == 0 && cw == ATT0) ? a.stamps + ((size_t)layer) * NSTX : nullptr);
         if (st) st[3] = wall_clock64();
         // ---- att_out (quantised by its producers) -> wo rows, x +=
-        if (cw == 0) {
+        if (cw == AGW) {
             unsigned val[9];
             gath_mark(ctl, lane, 1);
             sweep<9>(a.attg, 0, 512 + 16, tag_of(a.base, layer, 2), val, a.err, 700, lane);
@@ -425,32 +429,30 @@ __device__ __forceinline__ void consumer(const EArgs& a, char* smem, Ctl* ctl, i
             for (int k = 0; k < 8; ++k) xqw[64 * k + lane] = val[k];
             if (lane < 16) xs[lane] = __uint_as_float(val[8]);
         }
+        cbar<NCW>(ctl, phase, a.err, lane);
         if (st) st[6] = wall_clock64();
-        cbar(ctl, phase, a.err, lane);
-        load_act<16>(A, smem, lane);
-        if (cw < 2) {
+        if (cw < JO) {
+            load_act<16>(A, smem, lane);
             const float r = run_job<16>(a, smem, ctl, s0 + JQ + cw, A, lane);
             const int row = cu * 8 + cw * 4 + (lane >> 4);
             const float xn = xf[row] + r;
             if ((lane & 15) == 8) put_gran(a.xg, row, __float_as_uint(xn), tag_of(a.base, layer, 3));
         }
         if (st) st[7] = wall_clock64();
-        // ---- x -> RMSNorm -> quantise -> w1 | w3 rows -> SiLU(gate) * up
+        // ---- x -> RMSNorm -> quantise -> w1 | w3 rows (gate / up pairs, raw, into LDS)
         gather_x(3, a.norms + (size_t)layer * 2 * D + D);
         load_act<16>(A, smem, lane);
-        for (int jb = cw; jb < J13; jb += 3) {
-            const float r = run_job<16>(a, smem, ctl, s0 + JQ + JO + jb, A, lane);
-            const int ri = __float_as_int(r);
-            const float g0 = __int_as_float(__builtin_amdgcn_readlane(ri, 8)), u0 = __int_as_float(__builtin_amdgcn_readlane(ri, 24));
-            const float g1 = __int_as_float(__builtin_amdgcn_readlane(ri, 40)), u1 = __int_as_float(__builtin_amdgcn_readlane(ri, 56));
-            const float hv = swiglu(lane == 0 ? g0 : g1, lane == 0 ? u0 : u1);
-            if (lane < 2) ctl->hloc[jb * 2 + lane] = hv;
+        for (int jb = cw; jb < J13; jb += NCW) {
+            const float r = run_job<16>(a, smem, ctl, s0 + JQ + JO + jb, A, lane, (st && NCW == 3) ? st + NST + 8 * (jb / 3) : nullptr);
+            if ((lane & 15) == 8) ctl->hraw[jb * 4 + (lane >> 4)] = r;
         }
         if (st) st[10] = wall_clock64();
-        cbar(ctl, phase, a.err, lane);
-        // ---- h: per-CU maximum -> the group's four CUs -> quantised granules
+        cbar<NCW>(ctl, phase, a.err, lane);
+        // ---- h = SiLU(gate) * up (transformer.rs:617-620) for the CU's 32 values at once; per-CU maximum -> the group's four CUs -> quantised granules
         if (cw == 0) {
-            const float hv = lane < 32 ? ctl->hloc[lane] : 0.0f;
+            const int hl = lane & 31;
+            float hv = swiglu_t(ctl->hraw[2 * hl], ctl->hraw[2 * hl + 1], etab);
+            hv = lane < 32 ? hv : 0.0f;
             const float m1 = wave64_max(fabsf(hv));
             const unsigned t4 = tag_of(a.base, layer, 4);
             if (lane == 0) put_gran(a.hmaxg, cu, __float_as_uint(m1), t4);
@@ -465,24 +467,24 @@ __device__ __forceinline__ void consumer(const EArgs& a, char* smem, Ctl* ctl, i
             if ((cu & 3) == 0 && lane == 0) put_gran(a.hqg, 2048 + (cu >> 2), __float_as_uint(sc), t5);
         }
         if (st) st[11] = wall_clock64();
-        {
-            unsigned val[11];
-            const int first = cw * 704, count = cw < 2 ? 704 : 640 + 64;                                // the third wave also takes the 64 scales
+        if (cw < NHW) {
+            unsigned val[NGH];
+            const int first = cw * HCNT;
             gath_mark(ctl, lane, 1);
-            sweep<11>(a.hqg, first, count, tag_of(a.base, layer, 5), val, a.err, 900, lane);
+            sweep<NGH>(a.hqg, first, HCNT, tag_of(a.base, layer, 5), val, a.err, 900, lane);
             gath_mark(ctl, lane, -1);
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
+            for (int k = 0; k < NGH; ++k) {
                 const int i = first + 64 * k + lane;
-                if (64 * k + lane < count) { if (i < 2048) xqw[i] = val[k]; else xs[i - 2048] = __uint_as_float(val[k]); }
+                if (64 * k + lane < HCNT) { if (i < 2048) xqw[i] = val[k]; else xs[i - 2048] = __uint_as_float(val[k]); }
             }
         }
+        cbar<NCW>(ctl, phase, a.err, lane);
         if (st) st[12] = wall_clock64();
-        cbar(ctl, phase, a.err, lane);
         load_act<64>(A, smem, lane);
         // ---- w2 rows, x +=
-        for (int jb = cw; jb < J2; jb += 3) {
-            const float r = run_job<64>(a, smem, ctl, s0 + JQ + JO + J13 + jb, A, lane);
+        for (int jb = cw; jb < J2; jb += NCW) {
+            const float r = run_job<64>(a, smem, ctl, s0 + JQ + JO + J13 + jb, A, lane, (st && NCW == 3) ? st + NST + 48 + 8 * (jb / 3) : nullptr);
             const int row = cu * 8 + jb;
             const float xn = xf[row] + r;
             if (lane == 56) { put_gran(a.xg, row, __float_as_uint(xn), tag_of(a.base, layer + 1, 0)); if (layer == a.nl - 1) a.x_out[row] = xn; }
@@ -491,14 +493,14 @@ __device__ __forceinline__ void consumer(const EArgs& a, char* smem, Ctl* ctl, i
     }
 }
 
-__global__ __launch_bounds__(256, 1) void engine_kernel(const EArgs a) {
+template <int NCW> __global__ __launch_bounds__(64 * (1 + NCW), 1) void engine_kernel(const EArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Ctl* ctl = reinterpret_cast<Ctl*>(smem + OFF_CTL);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), cu = blockIdx.x;
     if (threadIdx.x < sizeof(Ctl) / 4) reinterpret_cast<unsigned*>(ctl)[threadIdx.x] = 0u;
     __syncthreads();
     if (wave == 0) loader(a, smem, ctl, cu, lane);
-    else consumer(a, smem, ctl, cu, wave - 1, lane);
+    else consumer<NCW>(a, smem, ctl, cu, wave - 1, lane);
 }
 
 // ================================================================================================================ host
@@ -562,10 +564,10 @@ static void h_matmul(float* out, const Mat& m, const int8_t* xq, const float* xs
 struct Layer { Mat qkv, wo, w13, w2; std::vector<float> n_att, n_ffn; };
 
 int main(int argc, char** argv) {
-    const int steps = argc > 1 ? atoi(argv[1]) : 16, thin = argc > 2 ? atoi(argv[2]) : 1, depth = argc > 3 ? atoi(argv[3]) : 4;
+    const int steps = argc > 1 ? atoi(argv[1]) : 16, thin = argc > 2 ? atoi(argv[2]) : 1, depth = argc > 3 ? atoi(argv[3]) : 4, ncw = argc > 5 ? atoi(argv[5]) : 7;
     const int P0 = 16, S = 64, CHECK = 3;
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
-    printf("engine: %s, %d CUs; Llama-3.2-1B Q8_0 shapes, %d layers per launch, positions %d..%d, loader thinning %d, depth %d\n", prop.name, prop.multiProcessorCount, NL, P0, P0 + steps - 1, thin, depth);
+    printf("engine: %s, %d CUs; Llama-3.2-1B Q8_0 shapes, %d layers per launch, positions %d..%d, loader thinning %d, depth %d, %d consumer waves per CU\n", prop.name, prop.multiProcessorCount, NL, P0, P0 + steps - 1, thin, depth, ncw);
     if (prop.multiProcessorCount < NCU) { printf("needs %d CUs\n", NCU); return 1; }
     std::vector<Layer> Ls(NL);
     for (auto& l : Ls) {
@@ -610,9 +612,11 @@ int main(int argc, char** argv) {
     const size_t n_gran = 2048 + 3072 + 1024 + 256 + 2112 + 64;
     CK(hipMalloc(&d_gran, n_gran * 8)); CK(hipMemset(d_gran, 0, n_gran * 8));
     CK(hipMalloc(&d_err, 4)); CK(hipMemset(d_err, 0, 4));
-    const size_t n_st = (size_t)2 * NL * 3 * NST;
+    const size_t n_st = (size_t)2 * NL * NSTX;
     CK(hipMalloc(&d_st, n_st * 8)); CK(hipMemset(d_st, 0, n_st * 8));
-    CK(hipFuncSetAttribute((const void*)engine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+    CK(hipFuncSetAttribute((const void*)engine_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+    CK(hipFuncSetAttribute((const void*)engine_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+    auto launch = [&](const EArgs& ea) { if (ncw == 3) hipLaunchKernelGGL(engine_kernel<3>, dim3(NCU), dim3(256), SMEM, 0, ea); else hipLaunchKernelGGL(engine_kernel<7>, dim3(NCU), dim3(512), SMEM, 0, ea); };
     EArgs a{};
     a.stream = d_stream; a.norms = d_norms; a.rope = (const float2*)d_rope; a.kc = d_kc; a.vc = d_vc;
     a.xg = d_gran; a.qkvg = d_gran + 2048; a.attg = a.qkvg + 3072; a.hmaxg = a.attg + 1024; a.hqg = a.hmaxg + 256; a.err = d_err; a.S = S; a.thin = thin; a.depth = depth;
@@ -623,7 +627,7 @@ int main(int argc, char** argv) {
         for (int s = 0; s < steps; ++s) {
             a.pos = P0 + s; a.x_in = d_xin + (size_t)s * D; a.x_out = d_xout + (size_t)s * D; a.base = base; base += (NL + 1) * 8;
             a.stamps = (stamps && s == steps / 2) ? d_st : nullptr;
-            hipLaunchKernelGGL(engine_kernel, dim3(NCU), dim3(256), SMEM, 0, a);
+            launch(a);
         }
     };
     auto reset_cache = [&]() { CK(hipMemcpy(d_kc, kc_dev.data(), kc_dev.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_vc, vc_dev.data(), vc_dev.size() * 4, hipMemcpyHostToDevice)); };
@@ -640,7 +644,7 @@ int main(int argc, char** argv) {
         CK(hipMemset(d_gran, 0, n_gran * 8)); reset_cache();
         float* d_dbg; CK(hipMalloc(&d_dbg, 4096 * 4)); CK(hipMemset(d_dbg, 0, 4096 * 4)); a.dbg = d_dbg;
         a.nl = 1; a.pos = P0; a.x_in = d_xin; a.x_out = d_xout; a.base = 1u << 20; a.stamps = nullptr;
-        hipLaunchKernelGGL(engine_kernel, dim3(NCU), dim3(256), SMEM, 0, a);
+        launch(a);
         CK(hipDeviceSynchronize());
         std::vector<u64> gr(n_gran); CK(hipMemcpy(gr.data(), d_gran, n_gran * 8, hipMemcpyDeviceToHost));
         const u64 *gx = gr.data(), *gqkv = gx + 2048, *gatt = gqkv + 3072, *ghmax = gatt + 1024, *ghq = ghmax + 256;
@@ -659,11 +663,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < D; ++i) if (memcmp(&dg[i], &x[i], 4)) { if (bx < 3) printf("   xf[%d] host %.9g device %.9g\n", i, x[i], dg[i]); ++bx; }
             for (int i = 0; i < 512; ++i) if (memcmp(&dg[D + i], &xq[4 * i], 4)) { if (bq < 3) { unsigned a_, b_; memcpy(&a_, &dg[D + i], 4); memcpy(&b_, &xq[4 * i], 4); printf("   xq word %d host %08x device %08x\n", i, b_, a_); } ++bq; }
             for (int i = 0; i < 16; ++i) if (memcmp(&dg[D + 512 + i], &xs[i], 4)) { if (bs < 3) printf("   xs[%d] host %.9g device %.9g\n", i, xs[i], dg[D + 512 + i]); ++bs; }
-            float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int j = 0; j < D / 8; ++j) for (int k = 0; k < 8; ++k) p[k] = p[k] + x[8 * j + k] * x[8 * j + k];
-            printf("debug CU 0 first prologue: xf %d of 2048 differ, xq %d of 512 words, xs %d of 16; ss device %.9g; chains host/device:", bx, bq, bs, dg[D + 528]);
-            for (int k = 0; k < 8; ++k) printf(" %.6g/%.6g", p[k], dg[D + 529 + k]);
-            printf("\n");
+            printf("debug CU 0 first prologue: xf %d of 2048 differ, xq %d of 512 words, xs %d of 16; 1 / rms device %.9g\n", bx, bq, bs, dg[D + 528]);
         }
         cmpf("q / k / v rows", gqkv, qkv.data(), QKV, tag_of(a.base, 0, 1));
         for (int hh = 0; hh < NH + NKV; ++hh) {
@@ -771,22 +771,22 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     CK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
-    printf("RESULT engine thin=%d depth=%d: %.2f us per layer (best of 5; %.1f us per 16-layer step at positions %d..%d), err %d, stream %.1f MB per layer = %.2f TB/s\n", thin, depth,
-           best * 1000.0f / steps / NL, best * 1000.0f / steps, P0, P0 + steps - 1, err, (double)NCU * SLOTS * SLOTB / 1e6, (double)NCU * SLOTS * SLOTB * NL * steps / (best * 1e-3) / 1e12);
+    printf("RESULT engine consumers=%d thin=%d depth=%d: %.2f us per layer (best of 5; %.1f us per 16-layer step at positions %d..%d), err %d, stream %.1f MB per layer = %.2f TB/s\n",
+           ncw, thin, depth, best * 1000.0f / steps / NL, best * 1000.0f / steps, P0, P0 + steps - 1, err, (double)NCU * SLOTS * SLOTB / 1e6, (double)NCU * SLOTS * SLOTB * NL * steps / (best * 1e-3) / 1e12);
     // ---- stamp table (100 MHz wall clock): mean over layers 1..15 of the stamped step
     std::vector<long long> stv(n_st); CK(hipMemcpy(stv.data(), d_st, n_st * 8, hipMemcpyDeviceToHost));
-    const char* nm[NST] = {"x gathered (16 KB sweep, waves 0-1)", "RMSNorm + quantise done", "qkv rows published", "attention done (CU 0: 2 heads)", "  q/k/v granules seen", "  softmax done",
-                           "att_out gathered (4 KB)", "wo rows published", "x gathered", "RMSNorm + quantise done", "w1|w3 rows done", "h: max hop + quantise published", "h gathered (16.5 KB, 3 waves)", "w2 rows published", "", ""};
-    const int order[] = {0, 1, 2, 4, 5, 3, 6, 7, 8, 9, 10, 11, 12, 13};
+    const char* nm[NST] = {"x gathered (16 KB of granules)", "  normalise + quantise done", "qkv rows published", "attention done (CU 0, 3 consumers only)", "  q/k/v granules seen", "  softmax done",
+                           "att_out gathered (4 KB)", "wo rows published", "x gathered (16 KB of granules)", "  normalise + quantise done", "w1|w3 rows done", "h: SiLU, max hop, quantise, published", "h gathered (16.5 KB)", "w2 rows published", "  RMS chain done", "  RMS chain done"};
+    const int order[] = {0, 14, 1, 2, 4, 5, 3, 6, 7, 8, 15, 9, 10, 11, 12, 13};
     for (int c = 0; c < 2; ++c) {
         printf("stamps, CU %d (%s), wave 0, us since the previous row (mean over layers 1..%d):\n", c == 0 ? 0 : 200, c == 0 ? "attention CU" : "plain CU", NL - 1);
-        for (int oi = 0; oi < 14; ++oi) {
+        for (int oi = 0; oi < 16; ++oi) {
             const int k = order[oi];
             double acc = 0; int n = 0;
             for (int l = 1; l < NL; ++l) {
-                const long long* st = &stv[(((size_t)c * NL + l) * 3 + 0) * NST];
+                const long long* st = &stv[((size_t)c * NL + l) * NSTX];
                 long long prev;
-                if (oi == 0) prev = stv[(((size_t)c * NL + l - 1) * 3 + 0) * NST + 13]; else prev = st[order[oi - 1]];
+                if (oi == 0) prev = stv[((size_t)c * NL + l - 1) * NSTX + 13]; else prev = st[order[oi - 1]];
                 if ((k == 4 || k == 5) && c == 1) continue;
                 if (k == 3 && c == 0) prev = st[5];
                 if (k == 3 && c == 1) prev = st[2];
@@ -795,8 +795,13 @@ int main(int argc, char** argv) {
             if (n) printf("  %-40s %6.2f\n", nm[k], acc / n);
         }
         double tot = 0; int n = 0;
-        for (int l = 1; l < NL; ++l) { const long long a0 = stv[(((size_t)c * NL + l - 1) * 3) * NST + 13], a1 = stv[(((size_t)c * NL + l) * 3) * NST + 13]; if (a0 && a1) { tot += (double)(a1 - a0) / 100.0; ++n; } }
+        for (int l = 1; l < NL; ++l) { const long long a0 = stv[((size_t)c * NL + l - 1) * NSTX + 13], a1 = stv[((size_t)c * NL + l) * NSTX + 13]; if (a0 && a1) { tot += (double)(a1 - a0) / 100.0; ++n; } }
         if (n) printf("  %-40s %6.2f\n", "layer (w2 published -> w2 published)", tot / n);
+        for (int j = 0; j < 9; ++j) {
+            double w = 0, d = 0, ch = 0, ahead = 0; int m = 0;
+            for (int l = 1; l < NL; ++l) { const long long* js = &stv[((size_t)c * NL + l) * NSTX + NST + 8 * j]; if (js[0] && js[3]) { w += (js[1] - js[0]) / 100.0; d += (js[2] - js[1]) / 100.0; ch += (js[3] - js[2]) / 100.0; ahead += (double)js[4]; ++m; } }
+            if (m) printf("    wave 0 %s job %d: wait for the slot %5.2f, reads + dots %5.2f, chain %5.2f us; loader %5.1f slots ahead at entry\n", j < 6 ? "w1|w3" : "w2", j < 6 ? j : j - 6, w / m, d / m, ch / m, ahead / m);
+        }
     }
     return err != 0;
 }

@@ -1545,7 +1545,7 @@ template <int HS> struct WaveGeom {
     static constexpr int NPASS = TW / 64;
     static constexpr size_t SMEM = (size_t)(2 * HS + TW + 16) * 4 + (size_t)HS4 * TW * 16;
 };
-constexpr int qa_wave_T(int hs) { return hs == 64 ? 64 * 4 : ((hs == 96 || hs == 128) ? 64 : 0); }   // 0: no wave class (Gemma's 256-wide heads)
+constexpr int qa_wave_T(int hs) { return hs == 64 ? 64 * 4 : ((hs == 96 || hs == 128) ? 128 : (hs == 256 ? 64 : 0)); }   // longest context (pos + 1) of the wave forms; 0: no wave class
 
 template <int HS, bool GEMMA>
 __device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
@@ -2308,6 +2308,301 @@ __device__ __forceinline__ void attention_multi_tag(const AttnArgs& a, const int
     if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The wave form for the WIDE heads (96 / 128: Phi-3.5, Llama-3.2-3B; 256: Gemma-2), round 6: FOUR waves per head.
+// What the one-wave form (attention_wave_tag) lost its time to was not arithmetic: one wave issued the whole prefetch of its head - 32 LDS-DMA
+// key loads + up to 128 value-row loads of 256 bytes at HS = 128 - which took 3 us to ISSUE, and the granule poll queued behind it: q / k / v
+// were seen 3.7 us after the last qkv row (profiles/r6_timeline_*: polled at 7.4 us, rows done at 3.6).  Here the workgroup's four waves share
+// the head by KEY RANGE: wave w owns keys kpw w .. kpw w + kpw - 1 with kpw = 16 below 64 positions and 32 up to 128 (the 256-wide heads: 16, to 64
+// positions) - their value rows in registers (ND * kpw loads per wave instead of ND * 64), their scores (one lane per key), their
+// exponentials and their products a_t v_t - and a quarter of the dim groups of the K tile's LDS-DMA for ALL keys.  The reference's sequential
+// chains stay whole: every wave runs the softmax sum over all keys itself (from the exponentials in LDS: identical bits, one barrier less than a
+// hand-over), wave 0 runs the value chain - its own keys from registers, then the other waves' products from LDS (they alias the K tile, dead
+// after the scores) in key order, then the new position's.  The new key never enters the tile: its lane reads it from the wave's own rotated
+// copy, so no wave waits for another's DMA to patch it.  Four lds_barrier()s.  Same operations in the same order per value as
+// attention_body: bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int HS> struct QuadGeom {
+    static constexpr int HS4 = HS / 4, ND = (HS + 63) / 64, NH2 = (HS / 2 + 63) / 64;
+    static constexpr int KPW = HS <= 128 ? 32 : 16, TWK = 4 * KPW;             // keys per wave at most, longest context
+    static constexpr int NPASS = TWK / 64;
+    static constexpr size_t SMEM = (size_t)(4 * 2 * HS + TWK + 16 + 32) * 4 + (size_t)HS4 * TWK * 16;
+    static_assert((size_t)3 * KPW * ND * 64 * 4 <= (size_t)HS4 * TWK * 16, "the products alias the K tile");
+};
+template <int HS, bool GEMMA>
+__device__ __forceinline__ void attention_quad_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
+    using Q = QuadGeom<HS>;
+    constexpr int HS4 = Q::HS4, ND = Q::ND, NH2 = Q::NH2, KPW = Q::KPW, TWK = Q::TWK, half = HS / 2;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int kpw = (KPW == 32 && pos >= 64) ? 32 : 16;             // keys per wave (uniform over the workgroup)
+    const int tb = kpw * wv;                                        // this wave's first key
+    const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul, kv_dim = a.n_kv_heads * HS;
+    const int T = pos + 1, S = a.seq_len;
+    float* base = reinterpret_cast<float*>(smem);
+    float* qs = base + wv * 2 * HS;                                 // this wave's rotated query
+    float* kn = qs + HS;                                            // ... raw, then rotated key of this position
+    float* att = base + 4 * 2 * HS;                                 // TWK + 16 exponentials (shared)
+    float* red = att + TWK + 16;                                    // hand-off words: [0..3] maxima, [4] a_pos
+    float4* kt = reinterpret_cast<float4*>(red + 32);               // [HS4][TWK] x 16 bytes (shared)
+    float* prod = reinterpret_cast<float*>(kt);                     // after the scores: [key - kpw][ND][64] products a_t * v_t of waves 1..3
+    float* kT = att_k_head(a, kvh, HS);
+    const float* vbase = a.v_cache + (size_t)a.layer * S * kv_dim + kvh * HS;
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[0] = wall_clock64();
+
+    // ---- RoPE terms; this wave's quarter of the K tile (all keys) and its own value rows: all before the first poll
+    float2 cs[NH2];
+#pragma unroll
+    for (int i = 0; i < NH2; ++i) { const int j = lane + 64 * i; cs[i] = *reinterpret_cast<const float2*>(a.rope + ((size_t)pos * half + (j < half ? j : 0)) * 2); }
+#pragma unroll
+    for (int p = 0; p < Q::NPASS; ++p) {
+        if (64 * p < pos) {                                         // wave-uniform (rows past the sequence are read as they lie in the cache: seq_len >= TWK)
+#pragma unroll
+            for (int gg = 0; gg < HS4 / 4; ++gg) {
+                const int g = wv * (HS4 / 4) + gg;
+                __builtin_amdgcn_global_load_lds((const LMRS_GLOBAL void*)(kT + ((size_t)g * S + 64 * p + lane) * 4),
+                                                 (__attribute__((address_space(3))) void*)(kt + g * TWK + 64 * p), 16, 0, 0);
+            }
+        }
+    }
+    float v[ND][KPW];
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vbase), 0, 0x7fffffff, 0x00020000);
+    const int vrow = kv_dim * 4, vb0 = tb * vrow;
+    auto vblock = [&](auto self, auto u0c) __attribute__((always_inline)) -> void {
+        constexpr int u0 = decltype(u0c)::value;
+        if constexpr (u0 < KPW) {
+            if (u0 < kpw && tb + u0 < pos) {                        // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) {
+                        const int d = lane + 64 * i;
+                        v[i][u0 + u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vrs, (d < HS ? d : 0) * 4, vb0 + (u0 + u) * vrow, 0));
+                    }
+                self(self, std::integral_constant<int, u0 + 16>());
+            }
+        }
+    };
+    vblock(vblock, std::integral_constant<int, 0>());
+#pragma unroll
+    for (int u = 0; u < KPW; ++u)
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { v[i][u] = (u < kpw && tb + u < pos) ? v[i][u] : 0.0f; asm volatile("" : "+v"(v[i][u])); }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[1] = wall_clock64();
+
+    // ---- q, raw k, v of this position: poll the granules (every wave: nothing is handed over before the scores)
+    unsigned long long xg[3 * ND];
+    {
+        const unsigned long long* gp[3 * ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int d = lane + 64 * i, dc = d < HS ? d : 0;
+            gp[3 * i] = tg.gran + h * HS + dc; gp[3 * i + 1] = tg.gran + tg.att_dim + kvh * HS + dc; gp[3 * i + 2] = tg.gran + tg.att_dim + tg.kv_dim + kvh * HS + dc;
+        }
+        auto sweep = [&](unsigned long long (&x)[3 * ND]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < 3 * ND; ++k) x[k] = __hip_atomic_load(gp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto fresh = [&](const unsigned long long (&x)[3 * ND]) __attribute__((always_inline)) {
+            unsigned bad = 0u;
+#pragma unroll
+            for (int k = 0; k < 3 * ND; ++k) bad |= (unsigned)(x[k] >> 32) ^ tg.tag;
+            return __all(bad == 0u) != 0;
+        };
+        unsigned long long xa[3 * ND], xb[3 * ND];
+        sweep(xa);
+        for (unsigned spins = 0;; ++spins) {
+            sweep(xb);
+            if (fresh(xa)) {
+#pragma unroll
+                for (int k = 0; k < 3 * ND; ++k) xg[k] = xa[k];
+                break;
+            }
+            sweep(xa);
+            if (fresh(xb)) {
+#pragma unroll
+                for (int k = 0; k < 3 * ND; ++k) xg[k] = xb[k];
+                break;
+            }
+            if (spins > kTagSpinMax || (spins & 1023) == 1023) {     // bounded: report and finish with garbage instead of hanging
+                const int e = __hip_atomic_load(tg.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e != 0 || spins > kTagSpinMax) {
+                    if (e == 0) __hip_atomic_store(tg.err, a.layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 3 * ND; ++k) xg[k] = xb[k];
+                    break;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (loads return in order: this wave's share of the key tile landed before the granules did)
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[2] = wall_clock64();
+    float vnew[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int d = lane + 64 * i;
+        vnew[i] = __uint_as_float((unsigned)xg[3 * i + 2]);
+        if (d < HS) { qs[d] = __uint_as_float((unsigned)xg[3 * i]); kn[d] = __uint_as_float((unsigned)xg[3 * i + 1]); }
+    }
+    // RoPE (transformer.rs:480-491): this lane owns both halves of pair j; every wave keeps its own rotated q and key, wave 0 writes the
+    // key to the cache (for the later steps)
+#pragma unroll
+    for (int i = 0; i < NH2; ++i) {
+        const int j = lane + 64 * i;
+        if (j < half) {
+            const float fcr = cs[i].x, fci = cs[i].y;
+            {
+                const float v0 = qs[j], v1 = qs[j + half];
+                const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+                qs[j] = a0 - a1; qs[j + half] = b0 + b1;
+            }
+            const float v0 = kn[j], v1 = kn[j + half];
+            const float a0 = v0 * fcr, a1 = v1 * fci, b0 = v0 * fci, b1 = v1 * fcr;
+            const float r0 = a0 - a1, r1 = b0 + b1;
+            kn[j] = r0; kn[j + half] = r1;
+            if (wv == 0) {
+                kT[(((size_t)(j >> 2) * S + pos) << 2) + (j & 3)] = r0;
+                kT[(((size_t)((j + half) >> 2) * S + pos) << 2) + ((j + half) & 3)] = r1;
+            }
+        }
+    }
+    lds_barrier();                                                  // every wave's share of the K tile has landed
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[3] = wall_clock64();
+
+    // ---- scores (transformer.rs:507-529): one lane per key of this wave, sequential dot over the head dims; the key of this position
+    // comes from the wave's own rotated copy (kn), every other key from the tile
+    int wpos = pos;
+    if constexpr (GEMMA) { const int wb = a.st->win_base; wpos = wb >= 0 ? wb : pos; }
+    const float sqrt_hs = sqrtf((float)HS), ninf = __uint_as_float(0xff800000u);
+    const bool mine = lane < kpw;
+    const int t = tb + (mine ? lane : 0);
+    float sc;
+    {
+        const float4* kb4 = (t == pos) ? reinterpret_cast<const float4*>(kn) : kt + t;
+        const int ks = (t == pos) ? 1 : TWK;
+        float score = 0.0f;
+        constexpr int GB = 4;
+        static_assert(HS4 % (2 * GB) == 0, "head size");
+        float4 ka[GB], qa[GB], kb[GB], qb[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) { ka[u] = kb4[u * ks]; qa[u] = reinterpret_cast<const float4*>(qs)[u]; }
+#pragma unroll
+        for (int g0 = 0; g0 < HS4; g0 += 2 * GB) {
+#pragma unroll
+            for (int u = 0; u < GB; ++u) { kb[u] = kb4[(g0 + GB + u) * ks]; qb[u] = reinterpret_cast<const float4*>(qs)[g0 + GB + u]; }
+            asm volatile("" : "+v"(score) : : "memory");
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                float pr;
+                pr = qa[u].x * ka[u].x; score = score + pr;
+                pr = qa[u].y * ka[u].y; score = score + pr;
+                pr = qa[u].z * ka[u].z; score = score + pr;
+                pr = qa[u].w * ka[u].w; score = score + pr;
+            }
+            if (g0 + 2 * GB < HS4) {
+#pragma unroll
+                for (int u = 0; u < GB; ++u) { ka[u] = kb4[(g0 + 2 * GB + u) * ks]; qa[u] = reinterpret_cast<const float4*>(qs)[g0 + 2 * GB + u]; }
+            }
+            asm volatile("" : "+v"(score) : : "memory");
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                float pr;
+                pr = qb[u].x * kb[u].x; score = score + pr;
+                pr = qb[u].y * kb[u].y; score = score + pr;
+                pr = qb[u].z * kb[u].z; score = score + pr;
+                pr = qb[u].w * kb[u].w; score = score + pr;
+            }
+        }
+        score = score / sqrt_hs;
+        if constexpr (GEMMA) {                                      // transformer.rs:518-526
+            score = score / 50.0f;
+            score = (float)tanh((double)score);
+            score = score * 50.0f;
+            score = score + (((unsigned)(wpos - t) <= 4096u) ? 0.0f : -2.3819763e38f);
+        }
+        sc = (mine && t < T) ? score : ninf;
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[4] = wall_clock64();
+    // ---- softmax (functional.rs:122-140): max (order-free), exp, sequential sum over ALL keys (run by every wave), divide
+    float mx = wave64_max(sc);
+    if (lane == 0) red[wv] = mx;
+    lds_barrier();                                                  // (also: every wave is done with the K tile)
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float e0 = expf_glibc_t((mine && t < T) ? sc - mx : 0.0f, etab);
+    const float ex = (mine && t < T) ? e0 : 0.0f;                   // the slots past T hold +0.0 (exact: the running sum is >= +0)
+    if (mine) att[t] = ex;
+    lds_barrier();
+    float sum;
+    {
+        const float ea = att[lane];                                 // keys 0 .. 63 (kpw = 16: all four waves' slots; the slots past 4 kpw are never added)
+        sum = wave_serial_sum(0.0f, ea, T >= 64 ? 4 : (T + 15) >> 4);
+        if constexpr (TWK > 64) {
+            if (T > 64) { const float eb = att[64 + lane]; sum = wave_serial_sum(sum, eb, (T - 64 + 15) >> 4); }
+        }
+    }
+    const float w = ex / sum;
+    const float wz = (mine && t < pos) ? w : 0.0f;                  // the chains below cover the earlier positions; this one follows from registers
+    const bool own_pos = pos >= tb && pos < tb + kpw;
+    if (own_pos) {                                                  // wave-uniform
+        const float ap = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), pos - tb));
+        if (lane == 0) red[4] = ap;
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[5] = wall_clock64();
+    // ---- weighted sum of values (transformer.rs:533-541), t ascending; this lane's dims
+    if (wv > 0) {                                                   // the products of this wave's keys, for wave 0 to add in order
+        float* dst = prod + (size_t)(tb - kpw) * ND * 64;
+#pragma unroll
+        for (int u0 = 0; u0 < KPW; u0 += 16) {
+            if (u0 < kpw && tb + u0 < pos) {                        // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wz), u0 + u));
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) dst[((u0 + u) * ND + i) * 64 + lane] = wt * v[i][u0 + u];
+                }
+            }
+        }
+        lds_barrier();
+        return;
+    }
+    float o[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] = 0.0f;
+#pragma unroll
+    for (int u0 = 0; u0 < KPW; u0 += 16) {
+        if (u0 < kpw && u0 < pos) {                                 // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float wt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wz), u0 + u));
+#pragma unroll
+                for (int i = 0; i < ND; ++i) { const float pr = wt * v[i][u0 + u]; o[i] = o[i] + pr; }
+            }
+        }
+    }
+    lds_barrier();
+    const float a_pos = red[4];
+    for (int k0 = 0; k0 < 3 * kpw; k0 += 8) {
+        if (kpw + k0 < pos) {                                       // wave-uniform; slots past pos hold +-0.0 products (weight +0.0, value 0.0): exact no-ops
+            float pb[8][ND];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < ND; ++i) pb[u][i] = prod[((k0 + u) * ND + i) * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < ND; ++i) o[i] = o[i] + pb[u][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int d = lane + 64 * i;
+        const float pr = a_pos * vnew[i];
+        o[i] = o[i] + pr;
+        if (d < HS) a.out[h * HS + d] = o[i];
+    }
+    if (a.dbg && lane == 0 && wv == 0 && blockIdx.x == 0) a.dbg[7] = wall_clock64();
+}
+
 constexpr int qa_chunk(int hs) { return (8192 / hs) & ~31; }        // V rows per LDS tile: 64 -> 128, 96 -> 64, 128 -> 64, 256 -> 32
 template <int HS> struct QaGeom { static constexpr int CH = qa_chunk(HS), NF = (CH * (HS / 4) + kBlock - 1) / kBlock; };
 
@@ -2318,7 +2613,7 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
     a.g = with_hot(a0.g, h_xin, h_wq, h_ws, h_rms_w, h_st, h_seq, h_out); a.t.st = h_st;
     const int nh = a.t.n_heads;
     if ((int)blockIdx.x < nh) {
-        if constexpr (WAVE) { if (HS != 64 && threadIdx.x >= 64) return; }     // one wave per head (64-wide heads: one wave per 64 keys, attention_multi_tag)
+        // (wave forms: the workgroup's waves share the head by key range - attention_pair_tag / attention_multi_tag for 64-wide heads, attention_quad_tag beyond)
         const uint64_t etab = exp2f_tab_lane();
         const int pos = a.t.st->pos;
         const AttTag tg{a.g.gran, *a.g.seq + 1u, a.g.att_dim, a.g.kv_dim, a.err};
@@ -2328,7 +2623,7 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
         const int nkv = a.t.n_kv_heads, bq = (int)blockIdx.x / nkv, br = (int)blockIdx.x - bq * nkv;
         const int head = br * (nh / nkv) + bq;
         if constexpr (WAVE && HS == 64) { if (pos < 128) attention_pair_tag<GEMMA>(a.t, head, pos, smem, etab, tg); else attention_multi_tag<GEMMA>(a.t, head, pos, smem, etab, tg); }
-        else if constexpr (WAVE) attention_wave_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
+        else if constexpr (WAVE) attention_quad_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
         else attention_body<HS, QaGeom<HS>::NF, false, false, GEMMA, false, true>(a.t, head, pos, smem, etab, AttPre(), tg);
     } else {
         gemv_static_body<N, L, PRO, EPI_QKV_TAG, kBlock, Q4>(a.g, smem, (int)blockIdx.x - nh, (int)gridDim.x - nh);
@@ -2358,8 +2653,9 @@ template <int N, int L, int PRO, bool Q4, int HS, bool GEMMA>
 static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t gsmem, int max_T, bool wave, hipStream_t s) {
     if constexpr (qa_wave_T(HS) > 0) {
         if (wave) {
-            constexpr size_t wsm = HS == 64 ? (kMultiSmem > kPairSmem ? kMultiSmem : kPairSmem) : WaveGeom<HS>::SMEM;
+            constexpr size_t wsm = HS == 64 ? (kMultiSmem > kPairSmem ? kMultiSmem : kPairSmem) : QuadGeom<HS>::SMEM;
             size_t smem = wsm > gsmem ? wsm : gsmem;
+            if (smem > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>));
             LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a);
             return hipGetLastError();
         }

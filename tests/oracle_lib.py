@@ -52,6 +52,9 @@ def lib():
         L.lmrs_ref_op_softmax.argtypes = [vp, sz]; L.lmrs_ref_op_softmax.restype = None
         L.lmrs_ref_op_matmul_q8.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]; L.lmrs_ref_op_matmul_q8.restype = None
         L.lmrs_ref_op_matmul_q4.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz]; L.lmrs_ref_op_matmul_q4.restype = None
+        L.lmrs_ref_op_matmul_q4_batched_faithful.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz]; L.lmrs_ref_op_matmul_q4_batched_faithful.restype = None
+        L.lmrs_ref_set_faithful_q9.argtypes = [C.c_int]; L.lmrs_ref_set_faithful_q9.restype = None
+        L.lmrs_ref_get_faithful_q9.restype = C.c_int
         L.lmrs_ref_op_quantize.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize.restype = None
         L.lmrs_ref_op_quantize_q4.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize_q4.restype = None
         L.lmrs_ref_op_expf.argtypes = [C.c_float]; L.lmrs_ref_op_expf.restype = C.c_float
@@ -283,3 +286,17 @@ class ProcessorOracle:
             lib().lmrs_ref_processor_destroy(self._h)
         except Exception:
             pass
+
+
+class faithful_q9:
+    """with faithful_q9(): batched forward_layer on Q4_0 files computes what the REFERENCE computes (token j's activations
+    taken at byte j*n of the packed tensor), not the token-by-token form the library implements.  Process-wide switch, restored on exit."""
+
+    def __enter__(self):
+        self.prev = lib().lmrs_ref_get_faithful_q9()
+        lib().lmrs_ref_set_faithful_q9(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().lmrs_ref_set_faithful_q9(self.prev)
+        return False

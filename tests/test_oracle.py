@@ -59,6 +59,14 @@ def test_against_reference_dump(golden_dir, name, cfg, seed):
         assert (emb.ravel().view(np.uint32) == ref_emb.view(np.uint32)).all(), f"{name}: fill_kv_cache residual differs from the reference"
         ref_fl = np.fromfile(os.path.join(ref_dir, name + ".fill_logits.f32"), "<f4")
         assert (o2.forward(int(toks[0]), len(prompt)).view(np.uint32) == ref_fl.view(np.uint32)).all()
+    else:
+        # Q4_0: what the reference returns from its batched forward_layer is the oracle's FAITHFUL mode (quirk Q9), not the default
+        with O.faithful_q9():
+            o2 = O.Oracle(img)
+            emb = o2.get_embeddings(prompt)
+            assert o2.fill_kv_cache(emb, 0) == len(prompt)
+        ref_emb = np.fromfile(os.path.join(ref_dir, name + ".fill.f32"), "<f4")
+        assert (emb.ravel().view(np.uint32) == ref_emb.view(np.uint32)).all(), f"{name}: faithful-Q9 fill_kv_cache residual differs from the reference"
 
 
 def test_thread_count_never_changes_bits():
@@ -141,3 +149,65 @@ def test_generate_matches_manual_loop():
         if s >= 3:
             out.append(nxt)
     assert out == list(map(int, toks))
+
+
+def test_q9_faithful_batched_matmul_q4_is_the_decode_form_of_token_2j():
+    """SURVEY Q9, pinned at the operator: the reference's batched matmul_q4 (functional.rs:216-250) takes token j's activation bytes at
+    j*n of a tensor that packs two elements per byte (token j's own nibbles lie at j*n/2), inside a zero-initialised buffer of sl*n bytes
+    (transformer.rs:424).  So its row j is the decode-form product of token 2j while 2j < sl, and an all-zero-scale sum (+0.0) beyond."""
+    rng = np.random.default_rng(9)
+    n, o, sl, gs = 256, 24, 5, 128
+    x = rng.standard_normal(sl * n).astype(np.float32)
+    w = rng.standard_normal(o * n).astype(np.float32)
+    wq, ws = O.quantize_q4(w)
+    xq_packed, xs_packed = O.quantize_q4(x)                       # sl*n/2 bytes, sl*n/gs scales
+    xq = np.zeros(sl * n, np.uint8); xq[:sl * n // 2] = xq_packed  # the reference's vec![0; total_shape]
+    xs = np.zeros(2 * sl * n // gs, np.float32); xs[:sl * n // gs] = xs_packed
+    out = np.full(sl * o, np.nan, np.float32)
+    O.lib().lmrs_ref_op_matmul_q4_batched_faithful(out.ctypes.data, xq.ctypes.data, xs.ctypes.data, wq.ctypes.data, ws.ctypes.data, n, o, gs, sl)
+    out = out.reshape(sl, o)
+    decode = np.stack([O.matmul_q4(xq_packed[t * n // 2:(t + 1) * n // 2], xs_packed[t * n // gs:(t + 1) * n // gs], wq, ws, n, o) for t in range(sl)])
+    for j in range(sl):
+        if 2 * j < sl:
+            assert (out[j].view(np.uint32) == decode[2 * j].view(np.uint32)).all(), j
+        else:
+            assert (out[j].view(np.uint32) == 0).all(), j        # (ival as f32) * w.s * 0.0 summed from 0.0: +0.0
+    assert (out[0].view(np.uint32) == decode[0].view(np.uint32)).all()
+    assert not (out[1].view(np.uint32) == decode[1].view(np.uint32)).all()   # ... which is NOT token 1's product
+
+
+@pytest.mark.parametrize("cfg", ["tiny-llama", "tiny-gemma"])
+def test_q9_deviation_of_fill_kv_cache_on_q4_files_is_pinned(cfg):
+    """The one place where the library (and the oracle's default mode) knowingly do NOT return the reference's values: fill_kv_cache with
+    more than one token on a Q4_0 file.  Default mode = every token through the decode form (== token-by-token fill, the identity the
+    HIP path is built on); faithful mode = the reference's arithmetic.  They agree on token 0 (its offset is 0 either way) and on nothing
+    after it; the size of the difference is written down here so that nobody 'fixes' either side by accident."""
+    img = S.build_image(cfg, S.Q4_0, 21)
+    toks = S.prompt_tokens(cfg, 6, 21)
+    a = O.Oracle(img)
+    e = a.get_embeddings(toks)
+    dim = a.args.dim
+    default = e.copy()
+    assert a.fill_kv_cache(default, 0) == 6
+    b = O.Oracle(img)
+    one_by_one = e.copy()
+    for i in range(len(toks)):
+        row = one_by_one[i * dim:(i + 1) * dim].copy()
+        b.fill_kv_cache(row, i)
+        one_by_one[i * dim:(i + 1) * dim] = row
+    if cfg != "tiny-gemma":                                                       # (Gemma's batched call has its own window quirk: transformer.rs:518-526 with the batch's first position)
+        assert (default.view(np.uint32) == one_by_one.view(np.uint32)).all()      # default mode == token by token
+    with O.faithful_q9():
+        c = O.Oracle(img)
+        faithful = e.copy()
+        assert c.fill_kv_cache(faithful, 0) == 6
+        # a single token is untouched by the quirk (xi = 0): decode steps are identical in both modes
+        d = O.Oracle(img); row = e[:dim].copy(); d.fill_kv_cache(row, 0)
+        assert (row.view(np.uint32) == default[:dim].view(np.uint32)).all()
+    assert not O.lib().lmrs_ref_get_faithful_q9()
+    D, F = default.reshape(6, dim), faithful.reshape(6, dim)
+    assert (D[0].view(np.uint32) == F[0].view(np.uint32)).all()                   # token 0: same arithmetic
+    differ = [(D[i].view(np.uint32) != F[i].view(np.uint32)).mean() for i in range(1, 6)]
+    assert min(differ) > 0.9, differ                                              # every later token: (almost) every value differs
+    rel = np.abs(D[1:] - F[1:]).max() / np.abs(D[1:]).max()
+    assert 0.05 < rel < 50.0, rel                                                 # ... by an O(1) relative amount: another token's activations, not noise

@@ -29,6 +29,7 @@
 //     saves a dependent kernel boundary (~1.2-1.9 us on this chip) per use.
 #include <hip/hip_ext.h>
 #include <mutex>
+#include <map>
 #include <set>
 #include <utility>
 
@@ -918,7 +919,11 @@ static StaticClass static_class(const GemvArgs& a, int pro, int epi) {
     int L = 0, nt = 256;
     if (!q4) {
         if (a.n == 2048) L = glu ? 16 : (a.o >= 8192 ? 8 : 32);
+#ifndef LMRS_PHI_QKV16
+        else if (a.n == 3072) L = (a.o >= 8192 && epi != EPI_QKV) ? 16 : 32;     // (qkv: the merged launch runs in one round of resident workgroups - 24 KB tiles balance its passes better than 48 KB ones)
+#else
         else if (a.n == 3072) L = a.o >= 8192 ? 16 : 32;
+#endif
         else if (a.n == 2304) L = epi == EPI_CLS ? 8 : 16;
         // (round 4, with the grouped quantiser: 32 lanes per row and 256 threads for w2 - half the waves to dispatch, twice the prologue per
         // lane - measured 423 us per step against 414: removed)
@@ -1545,7 +1550,8 @@ template <int HS> struct WaveGeom {
     static constexpr int NPASS = TW / 64;
     static constexpr size_t SMEM = (size_t)(2 * HS + TW + 16) * 4 + (size_t)HS4 * TW * 16;
 };
-constexpr int qa_wave_T(int hs) { return hs == 64 ? 64 * 4 : ((hs == 96 || hs == 128) ? 128 : (hs == 256 ? 64 : 0)); }   // longest context (pos + 1) of the wave forms; 0: no wave class
+// longest context (pos + 1) of the wave forms; 0: no wave class (Gemma's 256-wide heads: the four-wave form measured the same as the workgroup form there)
+constexpr int qa_wave_T(int hs) { return hs == 64 ? 64 * 4 : ((hs == 96 || hs == 128) ? 128 : 0); }
 
 template <int HS, bool GEMMA>
 __device__ __forceinline__ void attention_wave_tag(const AttnArgs& a, const int h, const int pos, char* smem, const uint64_t etab, const AttTag& tg) {
@@ -2313,8 +2319,8 @@ __device__ __forceinline__ void attention_multi_tag(const AttnArgs& a, const int
 // What the one-wave form (attention_wave_tag) lost its time to was not arithmetic: one wave issued the whole prefetch of its head - 32 LDS-DMA
 // key loads + up to 128 value-row loads of 256 bytes at HS = 128 - which took 3 us to ISSUE, and the granule poll queued behind it: q / k / v
 // were seen 3.7 us after the last qkv row (profiles/r6_timeline_*: polled at 7.4 us, rows done at 3.6).  Here the workgroup's four waves share
-// the head by KEY RANGE: wave w owns keys kpw w .. kpw w + kpw - 1 with kpw = 16 below 64 positions and 32 up to 128 (the 256-wide heads: 16, to 64
-// positions) - their value rows in registers (ND * kpw loads per wave instead of ND * 64), their scores (one lane per key), their
+// the head by KEY RANGE: wave w owns keys kpw w .. kpw w + kpw - 1 with kpw = 32 for positions 64 .. 127, where the kernel uses this form (16 below 64
+// positions, kept general) - their value rows in registers (ND * kpw loads per wave instead of ND * 64), their scores (one lane per key), their
 // exponentials and their products a_t v_t - and a quarter of the dim groups of the K tile's LDS-DMA for ALL keys.  The reference's sequential
 // chains stay whole: every wave runs the softmax sum over all keys itself (from the exponentials in LDS: identical bits, one barrier less than a
 // hand-over), wave 0 runs the value chain - its own keys from registers, then the other waves' products from LDS (they alias the K tile, dead
@@ -2623,7 +2629,12 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
         const int nkv = a.t.n_kv_heads, bq = (int)blockIdx.x / nkv, br = (int)blockIdx.x - bq * nkv;
         const int head = br * (nh / nkv) + bq;
         if constexpr (WAVE && HS == 64) { if (pos < 128) attention_pair_tag<GEMMA>(a.t, head, pos, smem, etab, tg); else attention_multi_tag<GEMMA>(a.t, head, pos, smem, etab, tg); }
-        else if constexpr (WAVE) attention_quad_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
+        else if constexpr (WAVE) {
+            // 96 / 128-wide heads: ONE wave per head below 64 positions (no barrier at all: 950 against 981 us per step on Llama-3.2-3B at the driver's
+            // 20 steps), the workgroup's four waves by key range from 64 to 127 (against the workgroup form there: -3 % per step) - profiles/r6_ab_attention_quad.txt
+            if (pos < 64) { if (threadIdx.x >= 64) return; attention_wave_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg); }
+            else attention_quad_tag<HS, GEMMA>(a.t, head, pos, smem, etab, tg);
+        }
         else attention_body<HS, QaGeom<HS>::NF, false, false, GEMMA, false, true>(a.t, head, pos, smem, etab, AttPre(), tg);
     } else {
         gemv_static_body<N, L, PRO, EPI_QKV_TAG, kBlock, Q4>(a.g, smem, (int)blockIdx.x - nh, (int)gridDim.x - nh);
@@ -2634,7 +2645,7 @@ __global__ __launch_bounds__(kBlock) void qkv_attn_kernel(LMRS_HOT_PARAMS, const
 #define LMRS_QA_TABLE(X)                                                                                                \
     X(2048, 32, PRO_RMS_QUANT, false, 64, false)      /* Llama-3.2-1B Q8_0 */                                            \
     X(3072, 32, PRO_RMS_QUANT, false, 128, false)     /* Llama-3.2-3B Q8_0 */                                            \
-    X(3072, 16, PRO_RMS_QUANT, false, 96, false)      /* Phi-3.5 Q8_0 */                                                 \
+    X(3072, 16, PRO_RMS_QUANT, false, 96, false) X(3072, 32, PRO_RMS_QUANT, false, 96, false)     /* Phi-3.5 Q8_0 */          \
     X(2304, 16, PRO_RMS_QUANT, false, 256, true) X(2304, 16, PRO_ADD_RMS_QUANT, false, 256, true)   /* Gemma-2-2B Q8_0 */  \
     X(2304, 8, PRO_RMS_QUANT, true, 256, true) X(2304, 8, PRO_ADD_RMS_QUANT, true, 256, true)       /* Gemma-2-2B Q4_0 */  \
     X(2048, 16, PRO_RMS_QUANT, true, 64, false)       /* Llama-3.2-1B Q4_0 */
@@ -2649,13 +2660,39 @@ bool qkv_attn_supported(const GemvArgs& g, int pro, const AttnArgs& t) {
 }
 int qkv_attn_wave_T(int head_size) { return qa_wave_T(head_size); }
 
+// The merged launch in ONE round of workgroups.  The GEMV part takes any grid <= its row passes (a workgroup walks its passes with a
+// double-buffered tile and runs the prologue once), but a workgroup that only STARTS when another one has left pays the whole prologue - 3 us
+// of norm chain and quantiser at dim 3072 - behind the first round: Llama-3.2-3B's 640 + 24 and Phi-3.5's 576 + 32 workgroups on 512 resident
+// slots (two per CU: registers) finished their rows at 6.8 us instead of 3.7, and the heads polled until then (profiles/r6_timeline_*).  The grid is
+// therefore capped at what is resident at once (occupancy query, cached per kernel and LDS size); the surplus passes go to workgroups as second passes.
+static int resident_grid_cap(const void* fn, size_t smem) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find({fn, smem});
+    if (it != cache.end()) return it->second;
+    int dev = 0, cus = 0, occ = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kBlock, smem) != hipSuccess || occ <= 0) { (void)hipGetLastError(); occ = 0; }
+    const int cap = occ * cus;                                      // 0: unknown - no cap
+    cache[{fn, smem}] = cap;
+    return cap;
+}
+static int qkv_attn_grid(const void* fn, size_t smem, int grid, int n_heads) {
+    static const int on = env_flag("LMRS_QKV_ONE_ROUND", 1);
+    const int cap = on ? resident_grid_cap(fn, smem) : 0;
+    return (cap > n_heads + 64 && grid > cap) ? cap : grid;
+}
+
 template <int N, int L, int PRO, bool Q4, int HS, bool GEMMA>
 static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t gsmem, int max_T, bool wave, hipStream_t s) {
     if constexpr (qa_wave_T(HS) > 0) {
         if (wave) {
-            constexpr size_t wsm = HS == 64 ? (kMultiSmem > kPairSmem ? kMultiSmem : kPairSmem) : QuadGeom<HS>::SMEM;
+            constexpr size_t wsm = HS == 64 ? (kMultiSmem > kPairSmem ? kMultiSmem : kPairSmem) : (QuadGeom<HS>::SMEM > WaveGeom<HS>::SMEM ? QuadGeom<HS>::SMEM : WaveGeom<HS>::SMEM);
             size_t smem = wsm > gsmem ? wsm : gsmem;
             if (smem > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>));
+            grid = qkv_attn_grid(reinterpret_cast<const void*>(qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), smem, grid, a.t.n_heads);
             LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, true>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a);
             return hipGetLastError();
         }
@@ -2664,6 +2701,7 @@ static hipError_t launch_qkv_attn_class(const QkvAttnArgs& a, int grid, size_t g
     size_t smem = attention_smem(HS, qa_chunk(HS), max_T);
     if (gsmem > smem) smem = gsmem;
     if (smem > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>));
+    grid = qkv_attn_grid(reinterpret_cast<const void*>(qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>), smem, grid, a.t.n_heads);
     LMRS_LAUNCH_GRID((qkv_attn_kernel<N, L, PRO, Q4, HS, GEMMA, false>), dim3(grid), kBlock, smem, s, LMRS_HOT_OF(a.g), a);
     return hipGetLastError();
 }

@@ -46,3 +46,29 @@ def test_bench_reads_the_profile_summaries_when_the_source_hash_matches():
     if rp["kernel_source_hash"] == h:
         assert r is not None and 300 < r < 700
     assert bench.pmc_traffic("llama-3.2-1b", "q4_0") is None or bench.pmc_traffic("llama-3.2-1b", "q4_0") > 0
+
+
+def test_hot_kernel_resources_have_not_moved():
+    """The per-kernel regression gate (no GPU): registers, scratch and the waves per SIMD they allow, of every hot kernel class of the BUILT
+    library (read from the gfx950 code objects: tools/kernel_resources.py), against the committed table tests/golden/kernel_resources.json.
+    A flag, launch-bound or source change that spills a class or drops its occupancy fails HERE, not in an artefact run on the GPU
+    (round 5: __launch_bounds__(512, 4) spilled Gemma's 9216-wide w2 class, 1139 -> 1088 tok/s, found by accident).  A deliberate change
+    is recorded with `python tools/kernel_resources.py --write` and shows up in the diff of the table."""
+    import lmrs_amd
+    from tools import kernel_resources as KR
+    lmrs_amd.build()                                            # (no-op when the library is fresh)
+    want = json.load(open(KR.TABLE))
+    got = KR.collect(hot_only=True)
+    assert set(got) == set(want), f"kernel classes added / removed: {sorted(set(got) ^ set(want))[:6]} - run tools/kernel_resources.py --write and review the diff"
+    bad = []
+    for name, w in want.items():
+        g = got[name]
+        if g["scratch"] != w["scratch"] or g["vgpr_spill"] != w["vgpr_spill"]:
+            bad.append(f"{name}: scratch {w['scratch']} -> {g['scratch']} bytes per lane, spilled VGPRs {w['vgpr_spill']} -> {g['vgpr_spill']}")
+        elif g["waves_per_simd"] != w["waves_per_simd"]:
+            bad.append(f"{name}: waves per SIMD {w['waves_per_simd']} -> {g['waves_per_simd']} (VGPRs {w['vgpr']}+{w['agpr']} -> {g['vgpr']}+{g['agpr']})")
+        elif abs(g["vgpr"] + g["agpr"] - w["vgpr"] - w["agpr"]) > 16:
+            bad.append(f"{name}: VGPRs {w['vgpr']}+{w['agpr']} -> {g['vgpr']}+{g['agpr']}")
+    assert not bad, "kernel resources moved:\n  " + "\n  ".join(bad[:12])
+    # the decode path's classes never touch scratch (only the unquantised f32 GEMV, off the hot path, does)
+    assert all(r["scratch"] == 0 for n, r in got.items() if "gemv_static_kernel" in n or "qkv_attn_kernel" in n)

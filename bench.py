@@ -158,16 +158,19 @@ def headline_then_guarded(headline, second, barrier, rank, limit_s, leave=os._ex
         try:
             ex_out = run()
             barrier()
+            figures = None
+            if rank == 0 and ex_out is not None:                # (inside the guard: a run that returns without these keys must not cost the headline line)
+                figures = {k: ex_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
+                figures["parallelism"] = ex_out["config"]["parallelism"]
+                figures["roofline"] = {k: ex_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}
         except BaseException as e:                              # noqa: BLE001 - the headline line must get out whatever happened here
             print(f"[rank {rank}] {key.replace('_', '-')} run failed: {type(e).__name__}: {e}", file=sys.stderr)
             emit_and_leave(f"the {key.replace('_', '-')} run failed on a rank: {type(e).__name__}")
             time.sleep(limit_s)                                 # (the watchdog thread is printing: wait for its exit)
             return out
         dog.cancel()
-        if rank == 0 and ex_out is not None:
-            out[key] = {k: ex_out.get(k) for k in ("value", "ms_per_step", "transport", "rccl_nranks", "parity")}
-            out[key]["parallelism"] = ex_out["config"]["parallelism"]
-            out[key]["roofline"] = {k: ex_out["roofline"].get(k) for k in ("frac", "redundant_bytes_per_step", "bytes_streamed_per_gpu_per_step", "step_split")}
+        if figures is not None:
+            out[key] = figures
     if printed.acquire(blocking=False) and rank == 0:
         print(json.dumps(out), flush=True)
     return out

@@ -53,6 +53,7 @@ struct DevLayer {
 };
 
 }  // namespace
+static int prefill_alloc(lmrs_ctx* c);       // (defined with the batched prefill below; lmrs_create calls it for RCCL row shards)
 
 struct lmrs_ctx {
     lmrs_args args{};
@@ -1047,7 +1048,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         c->qa_mode = 0;                         // the layers-only graph serves fill_kv_cache's token-by-token form at ANY position: separate kernels
         CK(capture(c, false, &c->g_layers));
         // from this position on a step uses the split attention (scores by key chunk, V by dim slice): graphs captured on first use
-        if (!c->dbg) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
+        if (!c->dbg || getenv("LMRS_ATT_SPLIT_POS")) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }     // (stamped steps: the split form only when asked for)
         // every graph a call below that threshold can need - per qkv + attention mode the single-step graph and the multi-step one -
         // is captured here rather than inside the first generate call that reaches the mode (a capture is milliseconds: on a
         // 128-token run that crosses the wave -> workgroup switch it was 3 % of the run)
@@ -1071,6 +1072,10 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     }
     // (peer-to-peer contexts capture their step graph in lmrs_p2p_connect, once the peers' arenas are known)
     if (sharded) { const char* e = getenv("LMRS_ATT_SPLIT_POS"); c->att_split_pos = e ? atoi(e) : 384; }
+    // Row shards over RCCL whose prefill is batched allocate its buffers (the token-batch blocks of the all-gathers among them) HERE: a shard
+    // that failed to allocate them inside its first fill_kv_cache would return before the exchange its peers are already waiting in
+    // (ncclAllGather has no time-out); at create the failure surfaces on every rank's own call, before any exchange exists.
+    if (c->tp_prefill && c->comm && (c->world > 1 || c->comm) && !c->cls_only) CK(prefill_alloc(c));
 #undef CK
 #undef HCK
     *out = c;

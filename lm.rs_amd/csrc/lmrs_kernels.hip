@@ -2732,7 +2732,6 @@ hipError_t launch_qkv_attn(const GemvArgs& g0, int pro, const AttnArgs& t0, int*
 // (max / exp / the sum chain / divide - the four copies run concurrently) and runs the V chains of its HS/4 dims, streaming
 // a quarter of the V bytes.  Same operations in the same order per value as attention_body: bit-identical.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAttSplitDims = 4;
 template <int HS, bool GEMMA>
 __global__ __launch_bounds__(kBlock) void attention_split_scores_kernel(const AttnArgs a, float* S) {
     __shared__ __attribute__((aligned(16))) float q[HS];
@@ -2788,52 +2787,133 @@ __global__ __launch_bounds__(kBlock) void attention_split_scores_kernel(const At
     if (t < T) S[(size_t)h * SQ + t] = score;
 }
 
+// Round 6: the value phase as a PIPELINE with specialised waves.  Waves 1-3 load a chunk of 256 value rows (the workgroup's slice of the head
+// dims), scale them by the weights and store the products TRANSPOSED - tile[d][t] - while wave 0, lane d, walks down row d of the PREVIOUS
+// chunk's tile with 16-byte reads (4 terms per read, the next batch of 16 in flight under the adds of the current one); one barrier per chunk,
+// two tiles.  Before: rows stored [t][d], the chain lane read one 4-byte term at a time, and the loads / stores / chains of a chunk ran one
+// after the other - 16.0 us per layer at 1024-1087 positions (profiles/r5_long_decode_kernel_stats.csv), 14.3 now.  The softmax sum runs in
+// registers (wave_serial_sum: 64 exponentials in the 64 lanes, one DPP-fed add per term; the next 64 are read under the adds).
+// What bounds it (profiles/r6_long_decode.txt, stamps at 1056 positions): the two chains, 2 x 1056 dependent adds, at 6.9 cycles per term
+// DPP-fed and 8-10 LDS-fed (a ds_read_b128 costs the issuing wave ~14 cycles per 4 terms on top of the adds) = 3.4 + 5.3 of the
+// workgroup's 12 us.  Measured and not kept: every value chain DPP-fed too, one output dim per wave - 4 waves x 512 workgroups: the
+// workgroup 10.6 us but the step +12 us (two chain waves per SIMD); 16 waves x 128 workgroups: value phase 9.4 us (four chain waves per SIMD
+// share its issue port).  Same operations in the same order per value: bit-identical.
+template <int HS> struct SplitGeom {
+    static constexpr int NSL = 4, HP = HS / NSL, HP4 = HP / 4, CHK = HS <= 128 ? 256 : 128, PITCH = CHK + 4;   // workgroups per head, dims per workgroup, keys per chunk (two tiles + 8192 weights within 160 KB), floats per tile row
+    static constexpr int NLD = 3 * 64, NSLOT = (CHK * HP4 + NLD - 1) / NLD;                                 // loader threads (waves 1-3), float4 slots per loader thread and chunk
+    static_assert(HP % 4 == 0 && HP <= 64, "dim slice");
+};
 template <int HS, bool GEMMA>
 __global__ __launch_bounds__(kBlock) void attention_split_values_kernel(const AttnArgs a, const float* S) {
-    constexpr int HP = HS / kAttSplitDims, RS = HP + 4;
-    static_assert(HP % 4 == 0, "dim slice");
+    using G = SplitGeom<HS>;
+    constexpr int HP = G::HP, HP4 = G::HP4, CHK = G::CHK, PITCH = G::PITCH, NLD = G::NLD, NSLOT = G::NSLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int h = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
+    const int h = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kv_mul = a.n_heads / a.n_kv_heads, kvh = h / kv_mul, kv_dim = a.n_kv_heads * HS;
-    const int pos = a.st->pos, T = pos + 1, CH = a.chunk;
+    const int pos = a.st->pos, T = pos + 1;
     const uint64_t etab = exp2f_tab_lane();
+    const bool stamp = a.dbg && tid == 0 && h == 0 && sl == 0;
+    if (stamp) a.dbg[0] = wall_clock64();
     float* red = reinterpret_cast<float*>(smem);            // 16 floats of reduction scratch
-    float* tile = red + 16;                                 // CH (+32) rows of RS floats
-    float* att = tile + (size_t)(CH + 32) * RS;             // T (+32 floats of zero padding, +32 of read-ahead)
+    float* tile = red + 16;                                 // 2 tiles of HP rows x PITCH floats: products a_t * v_t[d], [d][t - t0]
+    float* att = tile + 2 * HP * PITCH;                     // T exponentials, then weights (+ 128 floats of zero padding)
     const float* vbase = a.v_cache + (size_t)a.layer * a.seq_len * kv_dim + kvh * HS + sl * HP;
-    const int nchunks = (T + CH - 1) / CH;
-    float4 vreg[kAttF4];
-    att_gload<HP, kAttF4>(vreg, vbase, 0, T, CH, kv_dim);   // the first V chunk is in flight across the softmax
+    const int nchunks = (T + CHK - 1) / CHK;
+    // loader threads: slot i of loader thread lt is float4 number f = lt + i * NLD of the chunk (row f / HP4, dims 4 (f % HP4) ..)
+    const int lt = tid - 64;
+    float4 vreg[NSLOT];
+    auto vload = [&](int c) __attribute__((always_inline)) {
+        const int t0 = c * CHK, ct = (T - t0) < CHK ? (T - t0) : CHK;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int f = lt + i * NLD, row = f / HP4, c4 = f - row * HP4;
+            const int rr = row < ct ? row : ct - 1;                                     // (rows past the chunk: a harmless duplicate load, their products are zeroed)
+            vreg[i] = ld_f32x4<false>(vbase + (size_t)(t0 + rr) * kv_dim + c4 * 4);
+        }
+    };
+    auto vstore = [&](int c) __attribute__((always_inline)) {
+        const int t0 = c * CHK, ct = (T - t0) < CHK ? (T - t0) : CHK, nrows = (ct + 15) & ~15;       // the chain runs in batches of 16: rows ct .. nrows-1 hold +0.0
+        float* tl = tile + (c & 1) * HP * PITCH;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int f = lt + i * NLD, row = f / HP4, c4 = f - row * HP4;
+            if (row < nrows) {
+                const bool live = row < ct;
+                const float w = live ? att[t0 + row] : 0.0f;
+                float4 v = vreg[i];
+                v.x = live ? w * v.x : 0.0f; v.y = live ? w * v.y : 0.0f; v.z = live ? w * v.z : 0.0f; v.w = live ? w * v.w : 0.0f;
+                tl[(c4 * 4 + 0) * PITCH + row] = v.x; tl[(c4 * 4 + 1) * PITCH + row] = v.y;
+                tl[(c4 * 4 + 2) * PITCH + row] = v.z; tl[(c4 * 4 + 3) * PITCH + row] = v.w;
+            }
+        }
+    };
+    if (wave > 0) vload(0);                                 // the first V chunk is in flight across the softmax
     // softmax (functional.rs:122-140): max (order-free), exp, sequential sum, divide - as in attention_body
     float lmax = __uint_as_float(0xff800000u);
     for (int t = tid; t < T; t += kBlock) { const float sc = S[(size_t)h * a.seq_len + t]; att[t] = sc; lmax = fmaxf(lmax, sc); }
     lmax = wave64_max(lmax);
-    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    if (lane == 0) red[wave] = lmax;
     lds_barrier();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (stamp) a.dbg[1] = wall_clock64();
     for (int t0 = 0; t0 < T; t0 += kBlock) {                // whole waves call expf together (it shuffles)
         const int t = t0 + tid;
         const float e = expf_glibc_t(t < T ? att[t] - mx : 0.0f, etab);
         if (t < T) att[t] = e;
     }
-    if (tid < 32) att[T + tid] = 0.0f;
+    if (tid < 128) att[T + tid] = 0.0f;                     // +0.0 past the sequence: exact for a running sum that is >= +0 (128: the sum chain reads one block ahead)
     lds_barrier();
-    if (tid == 0) red[4] = serial_sum16<1>(0.0f, att, T);
+    if (stamp) a.dbg[2] = wall_clock64();
+    if (wave == 0) {                                        // the sum chain, 64 keys per step in the 64 lanes; the next 64 are read under the adds
+        float sum = 0.0f;
+        float e = att[lane];
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const float en = att[t0 + 64 + lane];
+            const int left = T - t0;
+            sum = wave_serial_sum(sum, e, left >= 64 ? 4 : (left + 15) >> 4);
+            e = en;
+        }
+        if (lane == 0) red[4] = sum;
+    }
     lds_barrier();
     const float sum = red[4];
+    if (stamp) a.dbg[4] = wall_clock64();
     for (int t = tid; t < T; t += kBlock) att[t] = att[t] / sum;
     lds_barrier();
-    // weighted sum of values (transformer.rs:533-541) for this workgroup's HP dims
+    if (stamp) a.dbg[5] = wall_clock64();
+    // weighted sum of values (transformer.rs:533-541) for this workgroup's HP dims: wave 0 chains chunk c while waves 1-3 prepare chunk c + 1
+    if (wave > 0) { vstore(0); if (nchunks > 1) vload(1); }
+    lds_barrier();
+    if (stamp) a.dbg[6] = wall_clock64();
     float o = 0.0f;
     for (int c = 0; c < nchunks; ++c) {
-        const int t0 = c * CH, ct = (T - t0) < CH ? (T - t0) : CH;
-        att_tstore<HP, kAttF4, true>(vreg, tile, att + t0, t0, T, CH, -1, nullptr);
-        lds_barrier();
-        if (c + 1 < nchunks) att_gload<HP, kAttF4>(vreg, vbase, t0 + CH, T, CH, kv_dim);
-        if (tid < HP) o = serial_sum16<RS, false>(o, tile + tid, ct);
+        if (wave == 0) {
+            const int t0 = c * CHK, ct = (T - t0) < CHK ? (T - t0) : CHK, nb = (ct + 15) >> 4;
+            const float4* row = reinterpret_cast<const float4*>(tile + (c & 1) * HP * PITCH + (lane < HP ? lane : 0) * PITCH);
+            float4 A[4], B[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) A[u] = row[u];
+            for (int b = 0; b < nb; b += 2) {               // (reads one or two batches past nb: inside the shared memory of the kernel, never added)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) B[u] = row[(b + 1) * 4 + u];
+                asm volatile("" : "+v"(o) : : "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { o = o + A[u].x; o = o + A[u].y; o = o + A[u].z; o = o + A[u].w; }
+                if (b + 1 >= nb) break;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) A[u] = row[(b + 2) * 4 + u];
+                asm volatile("" : "+v"(o) : : "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { o = o + B[u].x; o = o + B[u].y; o = o + B[u].z; o = o + B[u].w; }
+            }
+        } else if (c + 1 < nchunks) {
+            vstore(c + 1);
+            if (c + 2 < nchunks) vload(c + 2);
+        }
         lds_barrier();
     }
-    if (tid < HP) a.out[h * HS + sl * HP + tid] = o;
+    if (wave == 0 && lane < HP) a.out[h * HS + sl * HP + lane] = o;
+    if (stamp) a.dbg[7] = wall_clock64();
 }
 
 size_t attention_split_scratch_floats(int n_heads, int seq_len) { return (size_t)n_heads * seq_len; }
@@ -2841,13 +2921,12 @@ size_t attention_split_scratch_floats(int n_heads, int seq_len) { return (size_t
 template <int HS, bool GEMMA>
 static hipError_t launch_attention_split_hsg(const AttnArgs& a0, float* S, int n_key_chunks, hipStream_t s) {
     AttnArgs a = a0;
-    constexpr int HP = HS / kAttSplitDims;
-    a.chunk = 256;
-    if (a.chunk * (HP / 4) > kAttF4 * kBlock) return hipErrorInvalidValue;
-    const size_t smem = (size_t)(16 + (size_t)(a.chunk + 32) * (HP + 4) + ((a.seq_len + 3) & ~3) + 64) * 4;
+    using G = SplitGeom<HS>;
+    a.chunk = G::CHK;
+    const size_t smem = (size_t)(16 + 2 * G::HP * G::PITCH + ((a.seq_len + 3) & ~3) + 128) * 4;
     allow_big_lds(reinterpret_cast<const void*>(attention_split_values_kernel<HS, GEMMA>));
     LMRS_LAUNCH_GRID((attention_split_scores_kernel<HS, GEMMA>), dim3(a.n_heads, n_key_chunks), kBlock, 0, s, a, S);
-    LMRS_LAUNCH_GRID((attention_split_values_kernel<HS, GEMMA>), dim3(a.n_heads, kAttSplitDims), kBlock, smem, s, a, (const float*)S);
+    LMRS_LAUNCH_GRID((attention_split_values_kernel<HS, GEMMA>), dim3(a.n_heads, G::NSL), kBlock, smem, s, a, (const float*)S);
     return hipGetLastError();
 }
 // n_key_chunks: 256-key chunks covering the longest context this launch (graph) will see

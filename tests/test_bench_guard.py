@@ -18,11 +18,12 @@ lib = {{"value": 2000.0, "ms_per_step": 0.5, "transport": "p2p", "rccl_nranks": 
 def second():
     if mode == "raise": raise RuntimeError("peer-to-peer handshake: no flag from a peer")
     if mode == "hang": time.sleep(60)
+    if mode == "malformed": return {{"value": 5.0}} if rank == 0 else None      # a run that returns without `config` / `roofline`
     return lib if rank == 0 else None
 def third():
     if mode == "raise3": raise RuntimeError("split-out run failed")
     return dict(lib, value=3000.0, config={{"parallelism": "tp2 split-out"}}) if rank == 0 else None
-runs = second if mode in ("ok", "raise", "hang") else [("library_choice", second), ("tp_split_out", third)]
+runs = second if mode in ("ok", "raise", "hang", "malformed") else [("library_choice", second), ("tp_split_out", third)]
 out = bench.headline_then_guarded(lambda: head, runs, lambda: None, rank, 1.0)
 print("RETURNED", flush=True)
 """
@@ -74,3 +75,11 @@ def test_third_run_raises_the_first_two_are_printed():
     assert p.returncode == 0 and len(lines) == 1 and "RETURNED" not in p.stdout, (p.stdout, p.stderr)
     d = json.loads(lines[0])
     assert d["value"] == 1000.0 and d["library_choice"]["value"] == 2000.0 and d["tp_split_out"]["value"] is None and "RuntimeError" in d["tp_split_out"]["skipped"]
+
+
+def test_second_run_returns_without_its_figures_headline_still_printed():
+    """A run that comes back without `config` / `roofline` raises inside the guard, not after it: the headline line still gets out, once."""
+    p, lines = run("malformed", 0)
+    assert p.returncode == 0 and len(lines) == 1 and "RETURNED" not in p.stdout, (p.stdout, p.stderr)
+    d = json.loads(lines[0])
+    assert d["value"] == 1000.0 and d["library_choice"]["value"] is None and "KeyError" in d["library_choice"]["skipped"]

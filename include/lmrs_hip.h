@@ -279,19 +279,28 @@ int lmrs_sampler_create(uint32_t vocab_size, float temperature, float top_p, uin
 void lmrs_sampler_destroy(lmrs_sampler* s);
 int lmrs_sampler_sample(lmrs_sampler* s, float* logits, uint32_t* next);
 /* sample_topp (sampler.rs:67-106) from its sort on, for a caller that ran the temperature scaling, the softmax and the cutoff filter
- * elsewhere (lmrs_forward_sample runs them on the device): pairs = n0 candidates {f32 prob, u32 index} with
- * prob >= (1 - top_p) / (vocab_size - 1), in index order - what :74-80 leaves in probindex[0 .. n0). */
+ * elsewhere: pairs = n0 candidates {f32 prob, u32 index} with prob >= (1 - top_p) / (vocab_size - 1), in index order - what :74-80 leaves
+ * in probindex[0 .. n0).  A stand-alone host entry point: the library itself goes through lmrs_sampler_exps_prepare / _finish. */
 int lmrs_sampler_topp_pairs(lmrs_sampler* s, const void* pairs, size_t n0, uint32_t* next);
 /* Sampler::sample from the softmax's exponentials on (functional.rs:134-139, then sampler.rs:119-128): exps[i] = exp(logits[i] / temperature - max)
  * were formed elsewhere (lmrs_forward_sample forms them on the device); the sequential sum, the division, and sample_mult / sample_topp run here.
  * exps become the probabilities in place.  Same token and probabilities as lmrs_sampler_sample on the logits. */
 int lmrs_sampler_sample_exps(lmrs_sampler* s, float* exps, uint32_t* next);
+/* The same in two halves, for a caller that sorts sample_topp's candidates itself (lmrs_forward_sample: on the device, when most of the vocabulary
+ * passes the cutoff).  prepare: the sequential sum (functional.rs:134), the division (:137-139; exps become the probabilities in place) and, for a
+ * top-p sampler, the cutoff filter of sampler.rs:71-80 - *n0 candidates are left in the sampler's vector in index order (0 for sample_mult).
+ * finish: sorted_pairs = NULL: the reference's sort (:81) runs here; else the n0 candidates {f32 prob, u32 index} sorted by descending prob,
+ * ties in index order - exactly what :81 makes of them; then the merge with the stale rest of the vector, the cumulative cut and the draw. */
+int lmrs_sampler_exps_prepare(lmrs_sampler* s, float* exps, float* sum, float* cutoff, size_t* n0);
+int lmrs_sampler_exps_finish(lmrs_sampler* s, const float* probs, const void* sorted_pairs, uint32_t* next);
 int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, float* temperature, float* top_p, float* rnd);   /* rnd = random_f32(seed), the same on every call (:119) */
 /* Transformer::forward (src/transformer.rs:316) followed by Sampler::sample (src/sampler.rs:109-129) without the host ever touching the
  * logits: temperature 0 -> the argmax fused into the decode step; temperature != 0 -> the parallel part of the sampler on the device -
  * logits / temperature (:115), the maximum and exp(x - max) (functional.rs:126-133) - then the vocab_size exponentials cross to the host,
- * where lmrs_sampler_sample_exps runs the reference's sequential chains (the softmax sum, the running cdf) and sample_mult (:43-55) or
- * sample_topp (:67-106, the reference's default, chat.rs:28-31) over the sampler's persistent candidate vector.  Round 4 ran the chains
+ * where lmrs_sampler_exps_prepare / _finish run the reference's sequential chains (the softmax sum, the running cdf) and sample_mult (:43-55) or
+ * sample_topp (:67-106, the reference's default, chat.rs:28-31) over the sampler's persistent candidate vector; when more than 4096 candidates pass
+ * the cutoff (a flat distribution) their sort (:81) runs on the device - a bitonic network over the unique keys (prob, index): the same permutation
+ * as the reference's stable sort (7.05 -> 0.9 ms per token with 100 k candidates, profiles/r6_sampler_rate.txt).  Round 4 ran the chains
  * on the device as well (one wave, lane by lane): 1106 us per token against 1020 for the host sampler on copied logits - a dependent f32
  * add is ~1 ns on a host core and ~2.5 ns on one GPU lane; this split was measured at profiles/r5_sampler_rate.txt.  Same token as
  * lmrs_forward + lmrs_sampler_sample in every case.  One-GPU contexts (sharded ones copy the gathered logits). */

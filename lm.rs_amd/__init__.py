@@ -33,6 +33,7 @@ EXPORTS = [
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
     "lmrs_tokenizer_create", "lmrs_tokenizer_destroy", "lmrs_tokenizer_info", "lmrs_tokenizer_encode", "lmrs_tokenizer_decode",
     "lmrs_sampler_create", "lmrs_sampler_destroy", "lmrs_sampler_sample", "lmrs_sampler_sample_exps", "lmrs_sampler_topp_pairs",
+    "lmrs_sampler_exps_prepare", "lmrs_sampler_exps_finish",
 ]
 
 
@@ -122,6 +123,8 @@ def lib():
         L.lmrs_sampler_sample.argtypes = [vp, vp, C.POINTER(u32)]
         L.lmrs_sampler_topp_pairs.argtypes = [vp, vp, sz, C.POINTER(u32)]
         L.lmrs_sampler_sample_exps.argtypes = [vp, vp, C.POINTER(u32)]
+        L.lmrs_sampler_exps_prepare.argtypes = [vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_size_t)]
+        L.lmrs_sampler_exps_finish.argtypes = [vp, vp, vp, C.POINTER(u32)]
         L.lmrs_sampler_info.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lmrs_forward_sample.argtypes = [vp, u32, u32, vp, C.POINTER(u32)]
         L.lmrs_op_sample_mult.argtypes = [C.c_int, vp, sz, C.c_float, C.c_float, C.POINTER(u32)]
@@ -188,7 +191,8 @@ class Transformer:
         return n.value
 
     def forward_sample(self, token: int, pos: int, sampler: "Sampler") -> int:
-        """forward + Sampler::sample with the logits staying on the device (argmax / temperature + sample_mult; top-p goes through the host)"""
+        """forward + Sampler::sample: temperature 0 -> the fused argmax; else scaling / max / exp on the device, the sequential chains on the host, the sort of
+        many top-p candidates on the device again (lmrs_forward_sample)"""
         n = C.c_uint32()
         _chk(lib().lmrs_forward_sample(self._h, token, pos, sampler._h, C.byref(n)))
         return n.value

@@ -70,6 +70,8 @@ struct lmrs_ctx {
     uint32_t* tokens = nullptr; DevState* st = nullptr;
     unsigned long long* dbg = nullptr; int dbg_node = 0;     // LMRS_DEBUG_TIMELINE=1: 8 stamps per kernel node
     // pinned host
+    size_t topp_sort_min = 4096;                   // top-p candidates from which their sort runs on the device (LMRS_TOPP_DEVICE_SORT_MIN, read at create: a host stable sort of 4096 pairs is ~0.25 ms, the device route ~0.2 ms whatever the count)
+    unsigned long long* samp_keys = nullptr; float* samp_pairs = nullptr; void* h_pairs = nullptr; int samp_cap = 0;   // lmrs_forward_sample: the device sort of top-p candidates (allocated on first use)
     float* h_logits = nullptr; uint32_t* h_tok = nullptr; DevState* h_st = nullptr; unsigned h_st_next = 0;   // h_st: ring of kStateSlots pinned slots (an async copy may still be reading the previous one)
     hipGraphExec_t g_step = nullptr, g_layers = nullptr;
     // long contexts: step graphs whose attention is the split pair, one per context bucket (256-key chunks: 4, 8, 16, 32)
@@ -1040,6 +1042,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = a.head_size == 64 && a.seq_len >= 128 ? (int)a.seq_len : 0;
     }
     c->no_graph = getenv("LMRS_NO_GRAPH") != nullptr;
+    if (const char* e = getenv("LMRS_TOPP_DEVICE_SORT_MIN")) c->topp_sort_min = (size_t)atol(e);
     if (!sharded) { const int k = getenv("LMRS_STEPS_PER_GRAPH") ? atoi(getenv("LMRS_STEPS_PER_GRAPH")) : 4; c->multi_k = k < 1 ? 1 : (k > 64 ? 64 : k); }   // (measured: 4 steps per launch +1.5 % on a 20-step run, no effect on long runs)
     c->cls_tail = !sharded && !f32w && V < (1u << 20) - 1 && !(getenv("LMRS_CLS_TAIL") && atoi(getenv("LMRS_CLS_TAIL")) == 0);
     if (!sharded) {
@@ -1097,6 +1100,9 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     if (c->pfx_owned) { if (c->pfx_att) (void)hipFree(c->pfx_att); if (c->pfx_h) (void)hipFree(c->pfx_h); }
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) (void)hipHostFree(c->h_logits);
+    if (c->samp_keys) (void)hipFree(c->samp_keys);
+    if (c->samp_pairs) (void)hipFree(c->samp_pairs);
+    if (c->h_pairs) (void)hipHostFree(c->h_pairs);
     if (c->h_tok) (void)hipHostFree(c->h_tok);
     if (c->h_st) (void)hipHostFree(c->h_st);
     if (c->h_err) (void)hipHostFree(c->h_err);
@@ -1228,7 +1234,33 @@ extern "C" int lmrs_forward_sample(lmrs_ctx* c, uint32_t token, uint32_t pos, lm
     if (queue_err(c)) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     if (check_err(c)) return -1;
-    return lmrs_sampler_sample_exps(sampler, c->h_logits, next);
+    // the sequential sum, the division and the cutoff filter on the host (lmrs_text.cpp); the exponentials are still in c->logits on the device
+    float sum = 0.0f, cutoff = 0.0f; size_t n0 = 0;
+    if (lmrs_sampler_exps_prepare(sampler, c->h_logits, &sum, &cutoff, &n0)) return -1;
+    if (n0 < c->topp_sort_min || !(sum == sum)) return lmrs_sampler_exps_finish(sampler, c->h_logits, nullptr, next);
+    // many candidates (a flat distribution): their sort (sampler.rs:81) on the device - probabilities re-formed there from the same exponentials and
+    // the same sum by the same IEEE division, so the device finds the same n0 candidates (checked) - and only the sorted pairs come back
+    int N = sample_sort_min_n();
+    while ((size_t)N < n0) N <<= 1;
+    if (!c->samp_keys || c->samp_cap < N) {
+        if (c->samp_keys) { (void)hipFree(c->samp_keys); c->samp_keys = nullptr; }
+        if (c->samp_pairs) { (void)hipFree(c->samp_pairs); c->samp_pairs = nullptr; }
+        if (c->h_pairs) { (void)hipHostFree(c->h_pairs); c->h_pairs = nullptr; }
+        int cap = sample_sort_min_n();
+        while ((size_t)cap < n) cap <<= 1;                                               // once, for the whole vocabulary
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->samp_keys), (size_t)cap * 8 + 256));
+        HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->samp_pairs), (size_t)cap * 8));
+        HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c->h_pairs), (size_t)cap * 8 + 8, hipHostMallocDefault));
+        c->samp_cap = cap;
+    }
+    unsigned* count = reinterpret_cast<unsigned*>(c->samp_keys + c->samp_cap);           // (the word behind the keys)
+    HIP_OK(launch_sample_topp_sort(c->logits, (int)n, sum, cutoff, N, c->samp_keys, count, c->samp_pairs, c->stream));
+    HIP_OK(hipMemcpyAsync(c->h_pairs, c->samp_pairs, n0 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(reinterpret_cast<char*>(c->h_pairs) + (size_t)c->samp_cap * 8, count, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    unsigned dev_n0 = 0; memcpy(&dev_n0, reinterpret_cast<char*>(c->h_pairs) + (size_t)c->samp_cap * 8, 4);
+    if (dev_n0 != n0) return fail("lmrs_forward_sample: the device found " + std::to_string(dev_n0) + " top-p candidates, the host " + std::to_string(n0));
+    return lmrs_sampler_exps_finish(sampler, c->h_logits, c->h_pairs, next);
 }
 
 extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, size_t n, float* out) {

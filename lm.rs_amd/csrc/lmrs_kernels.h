@@ -133,6 +133,9 @@ hipError_t launch_dequant_rows(const void* q, const float* s, int q4, const uint
 struct SampleArgs { float* logits; int n; float temperature; float* part; };
 constexpr int kSampleGrid = 256;
 hipError_t launch_sample_exps(const SampleArgs& a, hipStream_t s);
+// sample_topp's candidate sort on the device (sampler.rs:67-81): see lmrs_kernels.hip.  N: power of two >= the candidates, >= sample_sort_min_n()
+hipError_t launch_sample_topp_sort(const float* exps, int n, float sum, float cutoff, int N, unsigned long long* keys, unsigned* count, float* pairs_out, hipStream_t s);
+int sample_sort_min_n();
 
 // thin kernels over the same device functions, for the lmrs_op_* unit-parity entry points
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st);

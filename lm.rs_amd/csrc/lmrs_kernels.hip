@@ -3025,6 +3025,91 @@ __global__ __launch_bounds__(kBlock) void sample_exp_kernel(const SampleArgs a, 
     if (!(x0 == x0)) mx = x0;                                    // max_val starts at x[0] and only moves on a strict `>`: a NaN there stays
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < a.n; i += gridDim.x * kBlock) a.logits[i] = expf_glibc(a.logits[i] - mx);
 }
+// ------------------------------------------------------------------------------------------------
+// sample_topp's sort (sampler.rs:67-81) on the device, for distributions where most of the vocabulary passes the cutoff (a flat one: > 64 k
+// candidates, 7 ms per token in a host stable sort).  The reference fills its candidates in INDEX order and sorts them stably by descending
+// probability; (prob, index) is therefore a total order, and any sort of the unique 64-bit keys (~bits(prob) << 32 | index) ascending gives
+// exactly that permutation - no stability needed, so an unordered compaction and a bitonic network do: bit-exact by construction.
+// prob = exp / sum is the IEEE quotient on both sides; the sum itself is the reference's sequential chain and stays on the host (the
+// caller passes it in).  keys: N = the power of two >= n0 entries, padded with ~0.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void sample_keys_kernel(const float* exps, int n, float sum, float cutoff, unsigned long long* keys, unsigned* count) {
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (blockIdx.x * kBlock + (int)threadIdx.x - lane); i0 < n; i0 += gridDim.x * kBlock) {      // whole waves stay together (ballot)
+        const int i = i0 + lane;
+        float p = 0.0f; bool in = false;
+        if (i < n) { p = exps[i] / sum; in = p >= cutoff; }                                                   // sampler.rs:75 (NaN: never a candidate)
+        const unsigned long long m = __ballot(in);
+        if (m) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(m));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (in) keys[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)(~__float_as_uint(p)) << 32) | (unsigned)i;
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void sample_pad_kernel(unsigned long long* keys, const unsigned* count, int N) {
+    for (int i = (int)*count + blockIdx.x * kBlock + (int)threadIdx.x; i < N; i += gridDim.x * kBlock) keys[i] = ~0ull;
+}
+constexpr int kSortBlock = 8192, kSortThreads = 1024;             // keys per workgroup in LDS (64 KB)
+// TAIL false: sorts every block of kSortBlock keys (stages k = 2 .. kSortBlock); TAIL true: the steps j = kSortBlock / 2 .. 1 of stage k
+template <bool TAIL>
+__global__ __launch_bounds__(kSortThreads) void sample_bitonic_local_kernel(unsigned long long* keys, int k_outer) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(smem);
+    const int base = blockIdx.x * kSortBlock;
+    for (int i = threadIdx.x; i < kSortBlock; i += kSortThreads) t[i] = keys[base + i];
+    __syncthreads();
+    for (int k = TAIL ? k_outer : 2; k <= (TAIL ? k_outer : kSortBlock); k <<= 1) {
+        for (int j = (TAIL ? kSortBlock : k) >> 1; j > 0; j >>= 1) {
+            for (int q = threadIdx.x; q < kSortBlock / 2; q += kSortThreads) {
+                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;        // the pair (i, i + j)
+                const bool up = ((base + i) & k) == 0;
+                const unsigned long long a = t[i], b = t[l];
+                if ((a > b) == up) { t[i] = b; t[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < kSortBlock; i += kSortThreads) keys[base + i] = t[i];
+}
+__global__ __launch_bounds__(kBlock) void sample_bitonic_global_kernel(unsigned long long* keys, int N, int j, int k) {
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < N / 2; q += gridDim.x * kBlock) {
+        const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+        const bool up = (i & k) == 0;
+        const unsigned long long a = keys[i], b = keys[l];
+        if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+    }
+}
+__global__ __launch_bounds__(kBlock) void sample_pairs_kernel(const unsigned long long* keys, const unsigned* count, float* pairs) {     // -> {prob, index} as sampler.rs:4-8
+    const int n0 = (int)*count;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n0; i += gridDim.x * kBlock) {
+        const unsigned long long key = keys[i];
+        pairs[2 * i] = __uint_as_float(~(unsigned)(key >> 32));
+        reinterpret_cast<unsigned*>(pairs)[2 * i + 1] = (unsigned)key;
+    }
+}
+// exps: the n exponentials on the device; keys: room for N = the power of two >= max(n0_host, kSortBlock) keys; count: one zeroed word.
+// pairs_out (device): the n0 sorted {prob, index} pairs.  All asynchronous on `s`.
+hipError_t launch_sample_topp_sort(const float* exps, int n, float sum, float cutoff, int N, unsigned long long* keys, unsigned* count, float* pairs_out, hipStream_t s) {
+    if (N < kSortBlock || (N & (N - 1)) != 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(count, 0, 4, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sample_keys_kernel, dim3(128), dim3(kBlock), 0, s, exps, n, sum, cutoff, keys, count);
+    hipLaunchKernelGGL(sample_pad_kernel, dim3(64), dim3(kBlock), 0, s, keys, (const unsigned*)count, N);
+    allow_big_lds(reinterpret_cast<const void*>(sample_bitonic_local_kernel<false>));
+    allow_big_lds(reinterpret_cast<const void*>(sample_bitonic_local_kernel<true>));
+    const size_t smem = (size_t)kSortBlock * 8;
+    hipLaunchKernelGGL(sample_bitonic_local_kernel<false>, dim3(N / kSortBlock), dim3(kSortThreads), smem, s, keys, 0);
+    for (int k = 2 * kSortBlock; k <= N; k <<= 1) {
+        for (int j = k >> 1; j >= kSortBlock; j >>= 1) hipLaunchKernelGGL(sample_bitonic_global_kernel, dim3(N / 2 / kBlock < 256 ? N / 2 / kBlock : 256), dim3(kBlock), 0, s, keys, N, j, k);
+        hipLaunchKernelGGL(sample_bitonic_local_kernel<true>, dim3(N / kSortBlock), dim3(kSortThreads), smem, s, keys, k);
+    }
+    hipLaunchKernelGGL(sample_pairs_kernel, dim3(128), dim3(kBlock), 0, s, (const unsigned long long*)keys, (const unsigned*)count, pairs_out);
+    return hipGetLastError();
+}
+
+int sample_sort_min_n() { return kSortBlock; }
 hipError_t launch_sample_exps(const SampleArgs& a, hipStream_t s) {
     if (a.n <= 0 || !a.logits || !a.part) return hipErrorInvalidValue;
     LMRS_LAUNCH_GRID(sample_scale_max_kernel, dim3(kSampleGrid), kBlock, 0, s, a);

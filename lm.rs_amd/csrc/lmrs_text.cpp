@@ -220,6 +220,7 @@ struct lmrs_sampler {
     struct ProbIndex { float prob; uint32_t index; };
     std::vector<ProbIndex> probindex;      // persists across calls, as in the reference (entries beyond n0 keep older values)
     bool rest_ordered = true;              // the vector is in descending order of prob (true from creation: all zeros; see topp_tail)
+    size_t pending_n0 = (size_t)-1;        // between lmrs_sampler_exps_prepare and _finish: this call's candidates sit in probindex[0 .. pending_n0)
 };
 
 namespace {
@@ -257,7 +258,7 @@ extern "C" int lmrs_sampler_info(const lmrs_sampler* s, uint32_t* vocab_size, fl
 }
 
 // sample_topp from its sort on (sampler.rs:81-105): probindex[0 .. n0) holds this call's candidates in index order
-static int topp_tail(lmrs_sampler* s, size_t n0, float rnd, uint32_t* next) {
+static int topp_tail(lmrs_sampler* s, size_t n0, float rnd, uint32_t* next, bool presorted = false) {
     // :81 sorts the WHOLE vector (stable, descending by prob), stale entries of earlier calls included.  The vector left that sort fully
     // ordered last time (and starts as all zeros), and this call rewrote only its first n0 entries: the rest is still ordered.  The
     // stable sort of the whole is therefore the stable sort of those n0 entries merged stably with the ordered rest (equal elements:
@@ -267,7 +268,9 @@ static int topp_tail(lmrs_sampler* s, size_t n0, float rnd, uint32_t* next) {
     const auto desc = [](const lmrs_sampler::ProbIndex& a, const lmrs_sampler::ProbIndex& b) { return a.prob > b.prob; };
     for (size_t i = 0; i < n0 && s->rest_ordered; ++i) if (!(s->probindex[i].prob == s->probindex[i].prob)) s->rest_ordered = false;
     if (s->rest_ordered) {
-        std::stable_sort(s->probindex.begin(), s->probindex.begin() + (ptrdiff_t)n0, desc);
+        // (presorted: the caller sorted this call's n0 candidates by (prob descending, index ascending) - what the stable sort of the index-ordered
+        // candidates gives - on the device: lmrs_forward_sample, launch_sample_topp_sort)
+        if (!presorted) std::stable_sort(s->probindex.begin(), s->probindex.begin() + (ptrdiff_t)n0, desc);
         std::inplace_merge(s->probindex.begin(), s->probindex.begin() + (ptrdiff_t)n0, s->probindex.end(), desc);
     } else std::stable_sort(s->probindex.begin(), s->probindex.end(), desc);
     if (n0 == 0) return text_fail("sample_topp: no candidate above the cutoff (the reference underflows n0 - 1 and panics)");
@@ -296,25 +299,45 @@ extern "C" int lmrs_sampler_topp_pairs(lmrs_sampler* s, const void* pairs, size_
 // exps[i] = exp(logits[i] / temperature - max) elsewhere (lmrs_forward_sample: on the device, the only part of the sampler that is parallel work).
 // What is left is the reference's two sequential chains - the softmax sum and the running cdf (or the candidates' sort) - and those run
 // here: a host core adds a dependent f32 in ~1 ns, one GPU lane in ~2.5 ns.  exps become the probabilities, as `logits` does in the reference.
-extern "C" int lmrs_sampler_sample_exps(lmrs_sampler* s, float* exps, uint32_t* next) {
-    if (!s || !exps || !next) return text_fail("NULL argument");
+extern "C" int lmrs_sampler_exps_prepare(lmrs_sampler* s, float* exps, float* sum_out, float* cutoff_out, size_t* n0_out) {
+    if (!s || !exps) return text_fail("NULL argument");
     if (s->temperature == 0.0f) return text_fail("temperature 0 is sample_argmax: no softmax to finish");
     const size_t n = s->vocab_size;
     float sum = 0.0f;
     for (size_t i = 0; i < n; ++i) sum = sum + exps[i];                              // functional.rs:134 (the adds of the exp loop, in its order)
     for (size_t i = 0; i < n; ++i) exps[i] = exps[i] / sum;                           // :137-139
+    size_t n0 = 0; float cutoff = 0.0f;
+    if (s->top_p > 0.0f && s->top_p < 1.0f) {                                         // sample_topp :67-80: the candidates, in index order
+        cutoff = (1.0f - s->top_p) / (float)(n - 1);
+        for (size_t i = 0; i < n; ++i)
+            if (exps[i] >= cutoff) { s->probindex[n0].index = (uint32_t)i; s->probindex[n0].prob = exps[i]; ++n0; }
+    }
+    s->pending_n0 = n0;
+    if (sum_out) *sum_out = sum;
+    if (cutoff_out) *cutoff_out = cutoff;
+    if (n0_out) *n0_out = n0;
+    return 0;
+}
+extern "C" int lmrs_sampler_exps_finish(lmrs_sampler* s, const float* probs, const void* sorted_pairs, uint32_t* next) {
+    if (!s || !probs || !next) return text_fail("NULL argument");
+    if (s->pending_n0 == (size_t)-1) return text_fail("lmrs_sampler_exps_finish without lmrs_sampler_exps_prepare");
+    const size_t n = s->vocab_size, n0 = s->pending_n0;
+    s->pending_n0 = (size_t)-1;
     const float rnd = random_f32(s->seed);
     if (s->top_p <= 0.0f || s->top_p >= 1.0f) {                                       // sample_mult :43-55
         float cdf = 0.0f;
-        for (size_t i = 0; i < n; ++i) { cdf = cdf + exps[i]; if (rnd < cdf) { *next = (uint32_t)i; return 0; } }
+        for (size_t i = 0; i < n; ++i) { cdf = cdf + probs[i]; if (rnd < cdf) { *next = (uint32_t)i; return 0; } }
         *next = (uint32_t)(n - 1);
         return 0;
     }
-    size_t n0 = 0;                                                                    // sample_topp :67-106
-    const float cutoff = (1.0f - s->top_p) / (float)(n - 1);
-    for (size_t i = 0; i < n; ++i)
-        if (exps[i] >= cutoff) { s->probindex[n0].index = (uint32_t)i; s->probindex[n0].prob = exps[i]; ++n0; }
-    return topp_tail(s, n0, rnd, next);
+    static_assert(sizeof(lmrs_sampler::ProbIndex) == 8, "pair layout");
+    if (sorted_pairs && n0) memcpy(s->probindex.data(), sorted_pairs, n0 * sizeof(lmrs_sampler::ProbIndex));
+    return topp_tail(s, n0, rnd, next, sorted_pairs != nullptr);
+}
+extern "C" int lmrs_sampler_sample_exps(lmrs_sampler* s, float* exps, uint32_t* next) {
+    if (!s || !exps || !next) return text_fail("NULL argument");
+    if (lmrs_sampler_exps_prepare(s, exps, nullptr, nullptr, nullptr)) return -1;
+    return lmrs_sampler_exps_finish(s, exps, nullptr, next);
 }
 
 // Sampler::sample (sampler.rs:109-129).  logits (vocab_size floats) are scaled and softmax-ed IN PLACE when temperature != 0, as

@@ -96,9 +96,9 @@ def test_forward_sample_matches_the_oracle(L):
 
 
 def test_topp_filter_on_peaked_and_flat_distributions(L):
-    """sample_topp's device front half on the real vocabulary size: a peaked distribution (a handful of candidates cross to the host), a flat
-    one (more than half the vocabulary passes the cutoff: the probabilities are copied instead) and stale candidates of an earlier, wider
-    call still in the sampler's persistent vector - the device route and the host route each against the ORACLE's sampler on the oracle's logits."""
+    """sample_topp through lmrs_forward_sample (exponentials on the device, the sequential sum, the cutoff filter and the draw on the host) on a
+    peaked and a flat distribution, with stale candidates of an earlier, wider call still in the sampler's persistent vector - the device route
+    and the host route each against the ORACLE's sampler on the oracle's logits."""
     rng = np.random.default_rng(5)
     img = S.build_image("mini-llama", S.Q8_0, seed=78)
     a = L.Transformer(img); b = L.Transformer(img); o = O.Oracle(img)
@@ -110,6 +110,40 @@ def test_topp_filter_on_peaked_and_flat_distributions(L):
             want = so.sample(o.forward(t, pos).copy())
             assert a.forward_sample(t, pos, sa) == want, (temperature, top_p, pos)
             assert sb.sample(b.forward(t, pos)) == want, (temperature, top_p, pos)
+
+
+@pytest.mark.parametrize("cfg,sort_min", [("mini-llama", 16), ("mini-llama-v40k", 16), ("mini-llama-v40k", 9000)])
+def test_topp_candidates_sorted_on_the_device(L, monkeypatch, cfg, sort_min):
+    """sample_topp's sort (sampler.rs:81) on the device - a bitonic network over the unique keys (prob descending, index ascending), i.e. the
+    permutation the reference's stable sort gives - forced on from 16 candidates: one sort block (vocabulary 4096) and several (40 000: the global
+    merge steps), flat and peaked distributions in turn on ONE sampler so that the merge with the stale rest of its vector runs too, wider calls
+    before narrower ones and back; sort_min 9000: calls above and below the switch interleave host-sorted and device-sorted states.  Against the
+    oracle's sampler on the oracle's logits, token by token."""
+    monkeypatch.setenv("LMRS_TOPP_DEVICE_SORT_MIN", str(sort_min))
+    rng = np.random.default_rng(6)
+    img = S.build_image(cfg, S.Q8_0, seed=79)
+    a = L.Transformer(img); o = O.Oracle(img)
+    V = a.args.vocab_size
+    for top_p in (0.9, 0.3):
+        samplers = {t: (L.Sampler(V, t, top_p, 4242), O.Sampler(V, t, top_p, 4242)) for t in (1.0, 0.05)}
+        for pos in range(24):
+            t = int(rng.integers(0, V))
+            lo = o.forward(t, pos).copy()
+            for temperature in ((1.0, 0.05) if pos % 3 else (0.05, 1.0)):
+                sa, so = samplers[temperature]
+                assert a.forward_sample(t, pos, sa) == so.sample(lo.copy()), (cfg, top_p, temperature, pos)
+    # ONE sampler fed flat and peaked distributions alternately: device-sorted candidates merged into the vector a host-sorted call left, and back
+    sa, so = L.Sampler(V, 0.7, 0.9, 5), O.Sampler(V, 0.7, 0.9, 5)
+    for pos in range(12):
+        t = int(rng.integers(0, V))
+        lo = o.forward(t, pos).copy()
+        if pos % 2:                                              # a dominant logit: a handful of candidates, sorted on the host (Sampler::sample on copied logits)
+            la = a.forward(t, pos).copy()                        # (the step itself runs on both sides: the later positions attend to this one)
+            k = int(rng.integers(0, V))
+            la[k] += 40.0; lo[k] += 40.0
+            assert sa.sample(la) == so.sample(lo), (cfg, pos)
+        else:                                                    # the model's own flat distribution through the device route
+            assert a.forward_sample(t, pos, sa) == so.sample(lo), (cfg, pos)
 
 
 @pytest.mark.parametrize("c", [1.0, 0.7978845608028654])

@@ -63,6 +63,8 @@ CONFIGS = {
     "mini-llama": ModelCfg("mini-llama", 2048, 8192, 2, 32, 64, 8, 4096, 256, 1e-5, 500000.0, LLAMA),
     # a vocabulary that is not a multiple of 4: its last two logits are never written by the reference (functional.rs:183)
     "mini-llama-v4102": ModelCfg("mini-llama-v4102", 2048, 8192, 2, 32, 64, 8, 4102, 256, 1e-5, 500000.0, LLAMA),
+    # a vocabulary of several sort blocks: the device sort of top-p candidates (lmrs_forward_sample) runs its global merge steps
+    "mini-llama-v40k": ModelCfg("mini-llama-v40k", 2048, 8192, 1, 32, 64, 8, 40000, 64, 1e-5, 500000.0, LLAMA),
     "mini-llama-long": ModelCfg("mini-llama-long", 2048, 8192, 2, 32, 64, 8, 4096, 2048, 1e-5, 500000.0, LLAMA),
     "mini-phi-long": ModelCfg("mini-phi-long", 3072, 8192, 2, 32, 96, 32, 4096, 1024, 1e-5, 10000.0, PHI),
     "mini-llama3b": ModelCfg("mini-llama3b", 3072, 8192, 2, 24, 128, 8, 4096, 256, 1e-5, 500000.0, LLAMA),

@@ -121,9 +121,13 @@ int lmrs_get_embeddings(const lmrs_ctx* ctx, const uint32_t* tokens, size_t n, f
 /* ---- Transformer::fill_kv_cache  (src/transformer.rs:672-684) ---------------------
  * Runs all layers over `n` embeddings (n*dim floats, updated in place exactly as the
  * reference mutates its argument) at positions curr_pos..curr_pos+n-1; no logits.
- * *new_pos = curr_pos + n.  The supported model shapes (Q8_0 / Q4_0) on one GPU run
- * forward_layer over the whole batch (int8 matrix-core GEMMs, transformer.rs:388-657 with
- * sl = n); other shapes go token by token through the decode kernels.  Same values either way. */
+ * *new_pos = curr_pos + n.  The supported model shapes (Q8_0 / Q4_0) on one GPU, and Q8_0 Llama /
+ * Phi shapes on row-split shards, run forward_layer over the whole batch (int8 matrix-core GEMMs,
+ * transformer.rs:388-657 with sl = n; row shards: two all-gathers of quantised token-batch blocks
+ * per layer); other shapes go token by token through the decode kernels.  Same values either way.
+ * One documented deviation from the reference: n > 1 on a Q4_0 file (INTEGRATION.md
+ * "Deviations": the reference multiplies token j with token 2j's nibbles; this computes the
+ * token-by-token result). */
 int lmrs_fill_kv_cache(lmrs_ctx* ctx, float* embeddings, uint32_t n, uint32_t curr_pos, uint32_t* new_pos);
 
 /* ---- the generation loop of src/bin/chat.rs:188-222 on token IDs, greedy ------------

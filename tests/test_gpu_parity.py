@@ -619,6 +619,26 @@ def test_gemma_2b_q4_batched_prefill_at_full_size(L):
                 assert_bit_equal(m.kv_row(which, l, pos), orc.kv_row(which, l, pos), f"kv[{which}] layer {l} pos {pos}")
 
 
+@pytest.mark.parametrize("cfg", ["mini-llama", "mini-gemma"])
+def test_fill_kv_cache_on_q4_files_is_the_decode_form_not_the_references_q9(L, cfg):
+    """The one documented deviation (INTEGRATION.md "Deviations"): the reference's batched matmul_q4 multiplies token j with token 2j's
+    nibbles.  The library returns what the oracle's DEFAULT mode returns - every token through the decode form - bit for bit, and NOT what the
+    oracle's reference-faithful mode returns (tests/test_oracle.py pins what that is); token 0, whose offset is 0 either way, agrees with both."""
+    img = S.build_image(cfg, S.Q4_0, seed=23)
+    toks = S.prompt_tokens(cfg, 40, 23)
+    m = L.Transformer(img); o = O.Oracle(img)
+    a = m.get_embeddings(toks); b = o.get_embeddings(toks)
+    assert m.fill_kv_cache(a, 0) == o.fill_kv_cache(b, 0) == 40
+    assert_bit_equal(a, b, f"{cfg} Q4_0: batched fill_kv_cache against the oracle's default (decode-form) mode")
+    with O.faithful_q9():
+        f = O.Oracle(img).get_embeddings(toks)
+        of = O.Oracle(img)
+        assert of.fill_kv_cache(f, 0) == 40
+    dim = m.args.dim
+    assert_bit_equal(a[:dim], f[:dim], "token 0 is the same arithmetic in both modes")
+    assert (bits(a[dim:]) != bits(f[dim:])).mean() > 0.9, "the library must NOT reproduce the reference's Q9 offsets"
+
+
 @pytest.mark.parametrize("cfg,n_steps", [("mini-llama-long", 700), ("mini-phi-long", 400)])
 def test_long_context_multi_chunk_attention(L, cfg, n_steps):
     """Positions beyond one LDS chunk of K/V rows (256 timesteps at head 64, 160 at head 96): the chunked score and

@@ -35,7 +35,10 @@ def main(fetch_csv, write_csv, out, model="llama-3.2-1b", qtype="q8_0"):
                   "hbm_bytes_per_launch": round((2 * fv + wv) * 1024)}
     gemv = {k: v for k, v in res.items() if "gemv" in k or "qkv_attn" in k}
     # one decode step of Llama-3.2-1B launches, per layer, one of each of the four layer GEMVs, and one classifier GEMV
-    doc = {"note": __doc__.split("usage")[0].strip(), "model": model, "qtype": qtype, "kernel_source_hash": kernel_source_hash(), "kernels": res,
+    # how the profiled run enqueued the step (tools/gpu_run.sh sets LMRS_NO_GRAPH=1 by default: rocprofv3 1.1 dies on the graph launches of most models);
+    # the published tok/s comes from graph replays of the SAME launches - recorded here so that nobody has to guess which mode a summary saw
+    mode = os.environ.get("LMRS_PROFILE_LAUNCH_MODE", "eager (LMRS_NO_GRAPH=1: the step's launches enqueued one by one)")
+    doc = {"note": __doc__.split("usage")[0].strip(), "model": model, "qtype": qtype, "kernel_source_hash": kernel_source_hash(), "launch_mode": mode, "kernels": res,
            "gemv_bytes_weighted_by_launch_count": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemv.values()) / max(1, sum(v["launches"] for v in gemv.values())))}
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):

@@ -209,6 +209,13 @@ int lmrs_step_info(const lmrs_ctx* ctx, uint32_t pos, int* n_launches, double* a
  * sl = n_tok) runs a launch of `o` rows over K = `n` with: the cost model of DESIGN.md section 4.1, host arithmetic only (no device is
  * touched).  0 x 0: fewer than 48 tokens - the direct kernels.  Inspection aid, no reference counterpart. */
 int lmrs_debug_gemm_tile(uint32_t n, uint32_t o, uint32_t n_tok, int q4, int* tile_rows, int* tile_tokens, int* waves);
+/* The batched w1 / w3 projection with the activation and the NEXT matmul's quantiser in its epilogue, as fill_kv_cache runs it from a few
+ * hundred tokens on (transformer.rs:588-630 with sl = n_tok: matmul_q8, SiLU(gate) * up or GELU(gate) * up, quantize): `wq` holds o rows of n
+ * int8 with gate / up rows interleaved (row 2i = w1's row i, row 2i + 1 = w3's), hq receives n_tok x o/2 int8 and hs n_tok x o/256 scales.
+ * Returns -1 with a message when the shape does not take the fused epilogue (lmrs_debug_gemm_tile: fewer than 128 rows x 128 tokens per
+ * tile).  Unit-parity aid, no reference counterpart. */
+int lmrs_debug_w13_quant(int device, int8_t* hq, float* hs, const int8_t* xq, const float* xs, const int8_t* wq, const float* ws,
+                         size_t n, size_t o, size_t n_tok, int gemma);
 
 /* ---- CLIP image tower of the multimodal models  (src/vision.rs) ---------------------------
  * lmrs_vision_create   <- VisionTransformer::new(data) -> (VisionTransformer, usize)   vision.rs:99-243

@@ -27,7 +27,7 @@ EXPORTS = [
     "lmrs_create", "lmrs_create_sharded", "lmrs_comm_unique_id", "lmrs_destroy", "lmrs_get_args", "lmrs_forward",
     "lmrs_forward_argmax", "lmrs_get_embeddings", "lmrs_fill_kv_cache", "lmrs_generate_greedy", "lmrs_last_error",
     "lmrs_op_matmul_q8", "lmrs_op_matmul_q4", "lmrs_op_quantize", "lmrs_op_quantize_q4", "lmrs_op_rmsnorm",
-    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv", "lmrs_debug_inject", "lmrs_last_fill_ms", "lmrs_debug_gemm_tile",
+    "lmrs_op_softmax", "lmrs_op_expf", "lmrs_op_tanh_cast", "lmrs_forward_sample", "lmrs_sampler_info", "lmrs_op_sample_mult", "lmrs_op_classifier_argmax", "lmrs_bench_gemv", "lmrs_bench_step", "lmrs_step_info", "lmrs_debug_timeline", "lmrs_debug_kv", "lmrs_debug_inject", "lmrs_last_fill_ms", "lmrs_debug_gemm_tile", "lmrs_debug_w13_quant",
     "lmrs_group_create", "lmrs_group_forward", "lmrs_shard_plan", "lmrs_shard_uses_graph", "lmrs_comm_ranks", "lmrs_p2p_handle", "lmrs_p2p_connect",
     "lmrs_vision_create", "lmrs_vision_destroy", "lmrs_vision_forward",
     "lmrs_processor_create", "lmrs_processor_destroy", "lmrs_processor_forward", "lmrs_processor_hd_transform", "lmrs_rope_terms",
@@ -132,6 +132,7 @@ def lib():
         L.lmrs_debug_inject.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.lmrs_last_fill_ms.argtypes = [vp, C.POINTER(C.c_double)]
         L.lmrs_debug_gemm_tile.argtypes = [u32, u32, u32, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.lmrs_debug_w13_quant.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, sz, sz, sz, C.c_int]
         L.lmrs_p2p_handle.argtypes = [vp, vp]
         L.lmrs_p2p_connect.argtypes = [vp, vp]
         L.lmrs_bench_step.argtypes = [vp, u32, C.c_int, vp, vp, vp]
@@ -324,6 +325,15 @@ def matmul_q8(xq, xs, wq, ws, n, o, gs=128, sl=1, device=0):
     _chk(lib().lmrs_op_matmul_q8(device, _p(out), _p(np.ascontiguousarray(xq, np.int8)), _p(np.ascontiguousarray(xs, np.float32)),
                                  _p(np.ascontiguousarray(wq, np.int8)), _p(np.ascontiguousarray(ws, np.float32)), n, o, gs, sl))
     return out
+
+
+def w13_quant(xq, xs, wq, ws, n, o, n_tok, gemma=False, device=0):
+    """The batched w1/w3 projection with the activation and the next matmul's quantiser in its epilogue (lmrs_debug_w13_quant):
+    -> (n_tok x o/2 int8, n_tok x o/256 scales)."""
+    hq = np.empty(n_tok * (o // 2), np.int8); hs = np.empty(n_tok * (o // 256), np.float32)
+    _chk(lib().lmrs_debug_w13_quant(device, _p(hq), _p(hs), _p(np.ascontiguousarray(xq, np.int8)), _p(np.ascontiguousarray(xs, np.float32)),
+                                    _p(np.ascontiguousarray(wq, np.int8)), _p(np.ascontiguousarray(ws, np.float32)), n, o, n_tok, int(bool(gemma))))
+    return hq, hs
 
 
 def matmul_q4(xq, xs, wq, ws, n, o, gs=128, device=0):

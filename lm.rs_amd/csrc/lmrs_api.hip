@@ -86,6 +86,7 @@ struct lmrs_ctx {
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool no_graph = false;                         // LMRS_NO_GRAPH=1 (read at create): steps are enqueued launch by launch (profiling aid, see launch_step)
+    bool no_fused_rope = false, no_fused_hq = false; // LMRS_NO_PREFILL_FUSION=1 (read at create; A/B aid): the batched prefill with RoPE and the h quantiser as launches of their own
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
     bool q4 = false, f32 = false;                  // f32: q_type None (unquantised weights, lmrs_f32.inc)
     // ---- row sharding.  Every shard owns whole output rows, so every float accumulation chain
@@ -1042,6 +1043,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         if (c->qa_wave_T > (int)a.seq_len) c->qa_wave_T = a.head_size == 64 && a.seq_len >= 128 ? (int)a.seq_len : 0;
     }
     c->no_graph = getenv("LMRS_NO_GRAPH") != nullptr;
+    c->no_fused_rope = c->no_fused_hq = getenv("LMRS_NO_PREFILL_FUSION") != nullptr;
     if (const char* e = getenv("LMRS_TOPP_DEVICE_SORT_MIN")) c->topp_sort_min = (size_t)atol(e);
     if (!sharded) { const int k = getenv("LMRS_STEPS_PER_GRAPH") ? atoi(getenv("LMRS_STEPS_PER_GRAPH")) : 4; c->multi_k = k < 1 ? 1 : (k > 64 ? 64 : k); }   // (measured: 4 steps per launch +1.5 % on a 20-step run, no effect on long runs)
     c->cls_tail = !sharded && !f32w && V < (1u << 20) - 1 && !(getenv("LMRS_CLS_TAIL") && atoi(getenv("LMRS_CLS_TAIL")) == 0);
@@ -1320,6 +1322,28 @@ static int prefill_alloc(lmrs_ctx* c) {
     return 0;
 }
 
+// RoPE + attention of a batch (transformer.rs:443-544 inside the sl loop) on the rows the qkv GEMM left in pf_q / pf_k / the V cache.  Block attention
+// (64-query blocks): the rotation rides in the score kernel's staging, which also writes the rotated keys to the cache (att_stage; round 6 - RoPE was a
+// launch of its own).  Otherwise (a few tokens, or score slabs beyond 1 GiB): the RoPE launch, then one workgroup per (token, head).
+static int prefill_attention(lmrs_ctx* c, AttnArgs& t, int m, int p0) {
+    if (attention_block_supported(t, m)) {
+        const size_t need = attention_block_scratch_floats(t.n_heads, m, p0 + m);
+        if (need <= ((size_t)1 << 28)) {                                       // <= 1 GiB of score slabs; longer contexts: per-token kernel
+            if (need > c->pf_att_cap) {
+                if (c->pf_att) { HIP_OK(hipStreamSynchronize(c->stream)); (void)hipFree(c->pf_att); c->pf_att = nullptr; c->pf_att_cap = 0; }
+                HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_att), need * 4)); c->pf_att_cap = need;
+            }
+            if (!c->no_fused_rope) t.k_raw = c->pf_k;
+            else HIP_OK(launch_rope_rows(c->pf_q, c->pf_k, c->k_cache, c->rope, t.n_heads, t.n_kv_heads, t.head_size, t.seq_len, t.layer, p0, m, c->stream));
+            HIP_OK(launch_attention_block(t, p0, m, c->pf_att, c->stream));
+            return 0;
+        }
+    }
+    HIP_OK(launch_rope_rows(c->pf_q, c->pf_k, c->k_cache, c->rope, t.n_heads, t.n_kv_heads, t.head_size, t.seq_len, t.layer, p0, m, c->stream));
+    HIP_OK(launch_attention_rows(t, p0, m, c->stream));
+    return 0;
+}
+
 // forward_layer(sl = m) for every layer over tokens at positions p0 .. p0+m-1 whose embeddings sit in c->pf_x.
 // Gemma: the branch outputs go to pf_t and "x += rmsnorm(branch)" (transformer.rs:563-568, 643-650) is folded into the
 // per-token prologue of the next GEMM (mode 2), as in the decode path; the last one is applied at the end.
@@ -1338,25 +1362,12 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
         g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
         HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
-        // RoPE, keys into the cache; attention per (token, head)                       (:443-544)
-        HIP_OK(launch_rope_rows(c->pf_q, c->pf_k, c->k_cache, c->rope, (int)a.n_heads, (int)a.n_kv_heads, (int)a.head_size, (int)a.seq_len, (int)l, p0, m, c->stream));
+        // RoPE, keys into the cache; attention                                         (:443-544)
         AttnArgs t{};
         t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
         t.n_heads = (int)a.n_heads; t.n_kv_heads = (int)a.n_kv_heads; t.head_size = (int)a.head_size; t.seq_len = (int)a.seq_len; t.layer = (int)l;
         t.gemma = gemma; t.st = c->st;
-        bool blocked = false;
-        if (attention_block_supported(t, m)) {
-            const size_t need = attention_block_scratch_floats(t.n_heads, m, p0 + m);
-            if (need <= ((size_t)1 << 28)) {                                   // <= 1 GiB of score slabs; longer contexts: per-token kernel
-                if (need > c->pf_att_cap) {
-                    if (c->pf_att) { HIP_OK(hipStreamSynchronize(c->stream)); (void)hipFree(c->pf_att); c->pf_att = nullptr; c->pf_att_cap = 0; }
-                    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_att), need * 4)); c->pf_att_cap = need;
-                }
-                HIP_OK(launch_attention_block(t, p0, m, c->pf_att, c->stream));
-                blocked = true;
-            }
-        }
-        if (!blocked) HIP_OK(launch_attention_rows(t, p0, m, c->stream));
+        if (prefill_attention(c, t, m, p0)) return -1;
         // quantize | Wo | x += ... (Gemma: -> pf_t)                                     (:550-576)
         HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, att, m, c->pf_xq, c->pf_xs, c->stream));
         g.wq = L.wo; g.ws = L.so; g.n = att; g.o = dim; g.out = gemma ? c->pf_t : c->pf_x;
@@ -1365,9 +1376,16 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         if (gemma) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_pre_ffn, c->pf_t, L.rms_post_att, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
         else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, nullptr, nullptr, eps, 0, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
         g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * hid; g.out = c->pf_h;
-        HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
         // quantize | W2 | x += ... (Gemma: -> pf_t)                                     (:630-654)
-        HIP_OK(launch_rows_prologue(c->pf_h, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, hid, m, c->pf_xq, c->pf_xs, c->stream));
+        if (!c->no_fused_hq && gemm_q8_hq_fused(dim, 2 * hid, m, q4 != 0)) {
+            // (the quantiser of h in w1/w3's epilogue: int8 rows + scales in the buffer the f32 rows would have taken)
+            g.hq = reinterpret_cast<int8_t*>(c->pf_h); g.hs = reinterpret_cast<float*>(reinterpret_cast<char*>(c->pf_h) + (size_t)kPrefillTokens * hid);
+            HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU_Q : EPI_SWIGLU_Q, c->stream));
+            g.xq = g.hq; g.xs = g.hs;
+        } else {
+            HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
+            HIP_OK(launch_rows_prologue(c->pf_h, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, hid, m, c->pf_xq, c->pf_xs, c->stream));
+        }
         g.wq = L.w2; g.ws = L.s2; g.n = hid; g.o = dim; g.out = gemma ? c->pf_t : c->pf_x;
         HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream));
     }
@@ -1403,23 +1421,10 @@ static int prefill_layers_tp(lmrs_ctx* c, int m, int p0) {
         g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
         g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
         HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
-        HIP_OK(launch_rope_rows(c->pf_q, c->pf_k, c->k_cache, c->rope, att / hs, kv / hs, hs, (int)a.seq_len, (int)l, p0, m, c->stream));
         AttnArgs t{};
         t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
         t.n_heads = att / hs; t.n_kv_heads = kv / hs; t.head_size = hs; t.seq_len = (int)a.seq_len; t.layer = (int)l; t.gemma = false; t.st = c->st;
-        bool blocked = false;
-        if (attention_block_supported(t, m)) {
-            const size_t need = attention_block_scratch_floats(t.n_heads, m, p0 + m);
-            if (need <= ((size_t)1 << 28)) {
-                if (need > c->pf_att_cap) {
-                    if (c->pf_att) { HIP_OK(hipStreamSynchronize(c->stream)); (void)hipFree(c->pf_att); c->pf_att = nullptr; c->pf_att_cap = 0; }
-                    HIP_OK(hipMalloc(reinterpret_cast<void**>(&c->pf_att), need * 4)); c->pf_att_cap = need;
-                }
-                HIP_OK(launch_attention_block(t, p0, m, c->pf_att, c->stream));
-                blocked = true;
-            }
-        }
-        if (!blocked) HIP_OK(launch_attention_rows(t, p0, m, c->stream));
+        if (prefill_attention(c, t, m, p0)) return -1;
         if (all_gather(c->pf_ao, att, c->pfx_att, c->pfb_att)) return -1;
         g.wq = L.wo; g.ws = L.so; g.n = c->att_full; g.o = dim; g.out = c->pf_x;
         HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
@@ -1797,6 +1802,22 @@ extern "C" int lmrs_op_matmul_q8(int device, float* xout, const int8_t* xq, cons
         HIP_OK(launch_gemv(g, PRO_PREQ, EPI_STORE, nullptr));
     }
     HIP_OK(hipMemcpy(xout, dout, sl * o * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lmrs_debug_w13_quant(int device, int8_t* hq, float* hs, const int8_t* xq, const float* xs, const int8_t* wq, const float* ws,
+                                    size_t n, size_t o, size_t n_tok, int gemma) {
+    if (op_begin(device)) return -1;
+    if (!gemm_q8_hq_fused((int)n, (int)o, (int)n_tok, false)) return fail("this w1/w3 shape does not take the quantising epilogue");
+    Scratch S; const size_t G = n / 128;
+    void *dx = S.get(n_tok * n), *dxs = S.get(n_tok * G * 4), *dw = S.get(o * n), *dws = S.get(o * G * 4), *dq = S.get(n_tok * (o / 2)), *ds = S.get(n_tok * (o / 256) * 4);
+    if (!ds) return fail("hipMalloc failed");
+    HIP_OK(hipMemcpy(dx, xq, n_tok * n, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dxs, xs, n_tok * G * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dw, wq, o * n, hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dws, ws, o * G * 4, hipMemcpyHostToDevice));
+    GemmArgs g{}; g.wq = dw; g.ws = static_cast<float*>(dws); g.xq = static_cast<const int8_t*>(dx); g.xs = static_cast<const float*>(dxs);
+    g.n = (int)n; g.o = (int)o; g.n_tok = (int)n_tok; g.hq = static_cast<int8_t*>(dq); g.hs = static_cast<float*>(ds);
+    HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU_Q : EPI_SWIGLU_Q, nullptr));
+    HIP_OK(hipMemcpy(hq, dq, n_tok * (o / 2), hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(hs, ds, n_tok * (o / 256) * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -21,7 +21,9 @@ enum Epilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV = 2, EPI_SWIGLU = 3, EPI_C
                 // image projector (processor.rs:234-342): + bias, tanh-GELU | + bias
                 EPI_BIAS_GELU = 9, EPI_BIAS = 10,
                 // merged qkv + attention launch: q / raw k / v leave as 8-byte {value, tag} granules (write-through), v also to its cache row
-                EPI_QKV_TAG = 11 };
+                EPI_QKV_TAG = 11,
+                // batched w1/w3 whose epilogue also quantises h for w2 (256-row tiles: one group of h per token and tile): GemmArgs::hq / hs
+                EPI_SWIGLU_Q = 12, EPI_GELU_Q = 13 };
 
 struct EmbedArgs {
     const void* emb_q; const float* emb_s; int q4;
@@ -173,7 +175,9 @@ struct GemmArgs {
     float* out;                          // STORE / RESID: [n_tok][o]; SWIGLU: [n_tok][o/2]; QKV: q [n_tok][att_dim]
     float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer, pos0;    // EPI_QKV
     const float* bias; const float* resid; float qscale;                         // CLIP epilogues: bias [o], residual [n_tok][o], sqrt(head_size)
+    int8_t* hq; float* hs;                                                       // EPI_SWIGLU_Q / EPI_GELU_Q: quantised h [n_tok][o/2] int8 + scales [n_tok][o/256]
 };
+bool gemm_q8_hq_fused(int n, int o, int n_tok, bool q4);                         // host only: this w1/w3 launch can take the quantising epilogue
 hipError_t launch_gemm_q8(const GemmArgs& a, int epi, hipStream_t s);
 struct GemmTile { int tm, tn, waves; };                                        // weight rows x tokens of a workgroup's output tile, waves per workgroup
 GemmTile gemm_q8_ring_tile(int n, int o, int n_tok, bool q4);                   // host only: the LDS-DMA ring kernel's tile for a launch of >= 48 tokens

@@ -58,6 +58,7 @@ def lib():
         L.lmrs_ref_op_quantize.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize.restype = None
         L.lmrs_ref_op_quantize_q4.argtypes = [vp, vp, vp, sz, sz]; L.lmrs_ref_op_quantize_q4.restype = None
         L.lmrs_ref_op_expf.argtypes = [C.c_float]; L.lmrs_ref_op_expf.restype = C.c_float
+        L.lmrs_ref_op_glu.argtypes = [vp, vp, sz, C.c_int]; L.lmrs_ref_op_glu.restype = None
         L.lmrs_ref_op_tanh_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double]; L.lmrs_ref_op_tanh_cast.restype = None
         L.lmrs_ref_rope_terms.argtypes = [C.POINTER(Args), u32, u32, f32p, f32p]; L.lmrs_ref_rope_terms.restype = None
         L.lmrs_ref_random_u32.argtypes = [C.c_uint64]; L.lmrs_ref_random_u32.restype = u32
@@ -167,6 +168,13 @@ def matmul_q4(xq, xs, wq, ws, n, o, gs=128):
     lib().lmrs_ref_op_matmul_q4(_p(out), _p(np.ascontiguousarray(xq, np.uint8)), _p(np.ascontiguousarray(xs, np.float32)),
                                 _p(np.ascontiguousarray(wq, np.uint8)), _p(np.ascontiguousarray(ws, np.float32)), n, o, gs)
     return out
+
+
+def glu(gate, up, gemma=False) -> np.ndarray:
+    """act(gate) * up elementwise (transformer.rs:607-624): SiLU, or Gemma's tanh-GELU."""
+    h = np.ascontiguousarray(gate, np.float32).copy(); u = np.ascontiguousarray(up, np.float32)
+    lib().lmrs_ref_op_glu(_p(h), _p(u), h.size, int(bool(gemma)))
+    return h
 
 
 def expf(x: float) -> float:

@@ -395,6 +395,29 @@ def test_matmul_q8_token_batch_on_matrix_cores(L, n, o, sl):
     assert_bit_equal(got, ref, f"gemm {n}x{o}, {sl} tokens")
 
 
+@pytest.mark.parametrize("n,o,sl,gemma", [(256, 16384, 130, False), (512, 16384, 500, False), (256, 18432, 300, True), (1024, 8192, 512, False)])
+def test_w13_with_the_quantiser_of_h_in_its_epilogue(L, n, o, sl, gemma):
+    """From a few hundred tokens on fill_kv_cache never forms the hidden vector in f32: the w1/w3 GEMM's 256-row tiles (gate / up rows
+    interleaved) hold one quantisation group of h per token, and the epilogue applies SiLU(gate) * up (Gemma: GELU) and the reference's
+    quantize (transformer.rs:588-630, quantization.rs:44-67).  Against the oracle's three steps - matmul_q8 over the batch, the
+    activation, quantize - the int8 values and the scales are bit-equal; both tile forms (256 x 128, and 256 x 64 where the cost model
+    asks for 128 x 128), ragged token counts, groups whose values span six orders of magnitude, an all-zero group."""
+    rng = np.random.default_rng(n + o + sl)
+    wq, ws = _rand_q8(rng, o, n)
+    ws = ws.reshape(o, -1)
+    ws[:512] *= np.float32(1e-3); ws[512:514] = 0.0; ws[1024:1280:2] *= np.float32(300.0)    # tiny groups of h, one exact zero inside a group, large gates
+    ws[768:1024] = 0.0                                                                        # ... and one group of h (values 384..511 of every token) that is all zeros: scale 0, NaN quotients -> 0
+    ws = ws.reshape(-1)
+    x = (rng.standard_normal(sl * n) * rng.uniform(0.1, 4.0, sl).repeat(n)).astype(np.float32)
+    xq, xs = O.quantize(x)
+    hq, hs = L.w13_quant(xq, xs, wq, ws, n, o, sl, gemma=gemma)
+    out = O.matmul_q8(xq, xs, wq, ws, n, o, sl=sl).reshape(sl, o)
+    h = O.glu(out[:, 0::2], out[:, 1::2], gemma=gemma)
+    rq, rs = O.quantize(h.reshape(-1))
+    assert_bit_equal(hs, rs, f"scales of h, {n}x{o}, {sl} tokens")
+    assert np.array_equal(hq, rq), f"quantised h, {n}x{o}, {sl} tokens: {(hq != rq).sum()} of {hq.size} differ"
+
+
 @pytest.mark.parametrize("cfg,q,n_tok,pos0", [("mini-llama", S.Q8_0, 70, 5), ("mini-llama3b", S.Q8_0, 33, 0), ("mini-phi", S.Q8_0, 140, 2),
                                               ("mini-llama-long", S.Q8_0, 600, 3), ("mini-llama", S.Q4_0, 70, 5), ("mini-gemma", S.Q8_0, 50, 3),
                                               ("mini-gemma", S.Q4_0, 75, 0),

@@ -1305,6 +1305,10 @@ int main(int argc, char** argv) {
 #ifdef MANYWAVE
     const Shape shapes[] = {{2048, 16384, 512, "w1/w3 of Llama-3.2-1B, 512 tokens"}, {2048, 16384, 256, "w1/w3, 256 tokens"}, {3072, 16384, 512, "w1/w3 of Llama-3.2-3B, 512 tokens"},
                             {8192, 2048, 512, "w2 of Llama-3.2-1B, 512 tokens"}, {2048, 3072, 512, "qkv, 512 tokens"}, {1024, 4096, 1154, "CLIP fc1 (2 crops x 577 rows)"}, {4096, 1024, 1154, "CLIP fc2"}};
+#elif defined(STRIDE)
+    // round 6: does the ROW STRIDE of the operands matter (K a power of two: every row of a tile starts a 128-byte group at the same address bits)?  us / (K / 128) = per group
+    const Shape shapes[] = {{8192, 2048, 512, "w2, 512 tokens, K = 8192"}, {8448, 2048, 512, "same, K = 8448 = 33 x 256"}, {8320, 2048, 512, "same, K = 8320 = 65 x 128 (odd multiple of 128: NOT a multiple of 256 - groups only)"},
+                            {2048, 2048, 512, "wo, 512 tokens, K = 2048"}, {2304, 2048, 512, "same, K = 2304 = 9 x 256"}, {8192, 2048, 256, "w2, 256 tokens, K = 8192"}, {8448, 2048, 256, "same, K = 8448"}};
 #elif defined(NARROW)
     const Shape shapes[] = {{8192, 2048, 256, "w2 of Llama-3.2-1B, 256 tokens"}, {8192, 2048, 128, "w2, 128 tokens"}, {2048, 2048, 256, "wo, 256 tokens"}, {2048, 2048, 128, "wo, 128 tokens"},
                             {2048, 3072, 256, "qkv, 256 tokens"}, {2048, 3072, 128, "qkv, 128 tokens"}, {2048, 16384, 128, "w1/w3, 128 tokens"}, {8192, 2048, 512, "w2, 512 tokens"}, {8192, 3072, 320, "w2 of Phi-3.5, 320 tokens"}};

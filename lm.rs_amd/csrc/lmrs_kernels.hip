@@ -2798,6 +2798,29 @@ __global__ __launch_bounds__(kBlock) void attention_split_scores_kernel(const At
 // workgroup's 12 us.  Measured and not kept: every value chain DPP-fed too, one output dim per wave - 4 waves x 512 workgroups: the
 // workgroup 10.6 us but the step +12 us (two chain waves per SIMD); 16 waves x 128 workgroups: value phase 9.4 us (four chain waves per SIMD
 // share its issue port).  Same operations in the same order per value: bit-identical.
+// One lane's chain over a row of float4 terms in LDS, 16 terms per batch, THREE batches of reads in flight under the adds of the current one (a ds_read_b128
+// returns after ~130-200 cycles, 16 dependent adds take ~64-80: one batch ahead left the chain waiting on every batch - 671 -> 664 us per step at 1032..1063
+// positions, 808 -> 800 at 1800; profiles/r6_ab_long_decode.txt, which also holds what did NOT help: the softmax sum as a one-lane LDS-fed chain, +4..+25 us
+// against the DPP-fed wave_serial_sum, and the chain lanes alone under EXEC, +-0).  nb batches are added; reads run up to three batches past nb.
+__device__ __forceinline__ float chain_rows16(float o, const float4* row, int nb) {
+    float4 R[4][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) R[k][u] = row[k * 4 + u];
+    for (int b = 0; b < nb; b += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (b + k >= nb) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) R[(k + 3) & 3][u] = row[(b + k + 3) * 4 + u];
+            asm volatile("" : "+v"(o) : : "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { o = o + R[k][u].x; o = o + R[k][u].y; o = o + R[k][u].z; o = o + R[k][u].w; }
+        }
+    }
+    return o;
+}
 template <int HS> struct SplitGeom {
     static constexpr int NSL = 4, HP = HS / NSL, HP4 = HP / 4, CHK = HS <= 128 ? 256 : 128, PITCH = CHK + 4;   // workgroups per head, dims per workgroup, keys per chunk (two tiles + 8192 weights within 160 KB), floats per tile row
     static constexpr int NLD = 3 * 64, NSLOT = (CHK * HP4 + NLD - 1) / NLD;                                 // loader threads (waves 1-3), float4 slots per loader thread and chunk
@@ -2888,24 +2911,11 @@ __global__ __launch_bounds__(kBlock) void attention_split_values_kernel(const At
     float o = 0.0f;
     for (int c = 0; c < nchunks; ++c) {
         if (wave == 0) {
+          {
             const int t0 = c * CHK, ct = (T - t0) < CHK ? (T - t0) : CHK, nb = (ct + 15) >> 4;
             const float4* row = reinterpret_cast<const float4*>(tile + (c & 1) * HP * PITCH + (lane < HP ? lane : 0) * PITCH);
-            float4 A[4], B[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) A[u] = row[u];
-            for (int b = 0; b < nb; b += 2) {               // (reads one or two batches past nb: inside the shared memory of the kernel, never added)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) B[u] = row[(b + 1) * 4 + u];
-                asm volatile("" : "+v"(o) : : "memory");
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { o = o + A[u].x; o = o + A[u].y; o = o + A[u].z; o = o + A[u].w; }
-                if (b + 1 >= nb) break;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) A[u] = row[(b + 2) * 4 + u];
-                asm volatile("" : "+v"(o) : : "memory");
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { o = o + B[u].x; o = o + B[u].y; o = o + B[u].z; o = o + B[u].w; }
-            }
+            o = chain_rows16(o, row, nb);                   // (reads up to three batches past nb: inside the shared memory of the kernel, never added)
+          }
         } else if (c + 1 < nchunks) {
             vstore(c + 1);
             if (c + 2 < nchunks) vload(c + 2);

@@ -86,6 +86,7 @@ struct lmrs_ctx {
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool no_graph = false;                         // LMRS_NO_GRAPH=1 (read at create): steps are enqueued launch by launch (profiling aid, see launch_step)
+    bool no_batched_prefill = false;               // LMRS_NO_BATCHED_PREFILL=1 (read ONCE, at create): fill_kv_cache and prompts go token by token through the decode kernels
     bool no_fused_rope = false, no_fused_hq = false; // LMRS_NO_PREFILL_FUSION=1 (read at create; A/B aid): the batched prefill with RoPE and the h quantiser as launches of their own
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
     bool q4 = false, f32 = false;                  // f32: q_type None (unquantised weights, lmrs_f32.inc)
@@ -141,7 +142,7 @@ constexpr int kPrefillTokens = 512;            // tokens per pass of the batched
 // exchange payload of the decode step), wo / w2 replicated, Llama / Phi head sizes; everything else feeds its tokens one by one.
 bool prefill_tp_shapes_ok(const lmrs_ctx* c) {
     const lmrs_args& a = c->args;
-    if (!c->qpay || !c->rep_out || c->cls_only || a.model_type == LMRS_GEMMA || getenv("LMRS_NO_BATCHED_PREFILL")) return false;
+    if (!c->qpay || !c->rep_out || c->cls_only || a.model_type == LMRS_GEMMA || c->no_batched_prefill) return false;
     if (!rows_prologue_supported((int)a.dim)) return false;
     if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
     return (c->att_dim + 2 * c->kv_dim) % 16 == 0 && c->kv_dim % 4 == 0 && a.dim % 16 == 0 && c->att_full % 128 == 0 && a.hidden_dim % 128 == 0;
@@ -850,6 +851,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     (void)hs;
 
     lmrs_ctx* c = new lmrs_ctx();
+    c->no_batched_prefill = getenv("LMRS_NO_BATCHED_PREFILL") != nullptr;
     c->args = a; c->lay = lay; c->device = device; c->q4 = a.q_type == LMRS_Q4_0; c->f32 = f32w;
     c->rank = rank; c->world = world; c->att_full = (int)att;
     c->att_dim = (int)att_l; c->kv_dim = (int)kv_l; c->dim_l = (int)dim_l; c->hid_l = (int)hid_l; c->voc_l = (int)voc_l;
@@ -1288,7 +1290,7 @@ extern "C" int lmrs_get_embeddings(const lmrs_ctx* cc, const uint32_t* tokens, s
 // everything else takes the token-by-token path below (same results).
 static bool prefill_batched_ok(const lmrs_ctx* c) {
     const lmrs_args& a = c->args;
-    if (getenv("LMRS_NO_BATCHED_PREFILL")) return false;
+    if (c->no_batched_prefill) return false;
     // (a "cls" shard runs the layers whole: the batched path applies to it as to a single GPU, every shard filling its own cache)
     const bool whole_layers = c->cls_only || (c->world == 1 && !c->comm && c->g_layers);
     if ((a.q_type != LMRS_Q8_0 && a.q_type != LMRS_Q4_0) || !whole_layers) return false;

@@ -441,6 +441,27 @@ def test_fill_kv_cache_batched_prefill(L, cfg, q, n_tok, pos0):
         t = int(O.lib().lmrs_ref_argmax(lo.ctypes.data, lo.size))
 
 
+@pytest.mark.parametrize("q,n_tok,pos0", [(S.Q8_0, 150, 7), (S.Q4_0, 90, 0)])
+def test_gemma_batched_attention_in_its_long_batch_forms(L, monkeypatch, q, n_tok, pos0):
+    """Gemma-2's block attention picks its forms by how full the chip is: up to a few hundred tokens 32-key score chunks on 8 waves and
+    32-dim value slices (what every other Gemma test here runs), beyond that 64-key chunks on 4 waves and 64-dim slices.
+    LMRS_ATT_LONG_BATCH_FORMS forces the latter at a length the CPU path finishes quickly: the same bit-equality, RoPE in the staging,
+    soft-cap and window term included, with and without keys from an earlier call in the cache."""
+    monkeypatch.setenv("LMRS_ATT_LONG_BATCH_FORMS", "1")
+    img = S.build_image("mini-gemma", q, seed=29)
+    m = L.Transformer(img); orc = O.Oracle(img)
+    if pos0:
+        warm = S.prompt_tokens("mini-gemma", pos0, 5)
+        a0 = m.get_embeddings(warm); b0 = orc.get_embeddings(warm)
+        assert m.fill_kv_cache(a0, 0) == orc.fill_kv_cache(b0, 0) == pos0
+    toks = S.prompt_tokens("mini-gemma", n_tok, 29)
+    a = m.get_embeddings(toks); b = orc.get_embeddings(toks)
+    assert m.fill_kv_cache(a, pos0) == orc.fill_kv_cache(b, pos0) == pos0 + n_tok
+    assert_bit_equal(a, b, "residual stream after the batched layers (long-batch attention forms)")
+    lo = orc.forward(3, pos0 + n_tok)
+    assert_bit_equal(m.forward(3, pos0 + n_tok), lo, "decode on the prefilled cache")
+
+
 @pytest.mark.parametrize("cfg,n_tok,pos0", [("mini-llama", 150, 9), ("mini-llama3b", 70, 0)])
 def test_batched_attention_with_memory_resident_scores(L, monkeypatch, cfg, n_tok, pos0):
     """Beyond 2048 keys the block softmax keeps its scores in the slab instead of LDS; LMRS_ATT_LDS_KEYS forces that variant at a

@@ -121,10 +121,11 @@ int lmrs_get_embeddings(const lmrs_ctx* ctx, const uint32_t* tokens, size_t n, f
 /* ---- Transformer::fill_kv_cache  (src/transformer.rs:672-684) ---------------------
  * Runs all layers over `n` embeddings (n*dim floats, updated in place exactly as the
  * reference mutates its argument) at positions curr_pos..curr_pos+n-1; no logits.
- * *new_pos = curr_pos + n.  The supported model shapes (Q8_0 / Q4_0) on one GPU, and Q8_0 Llama /
- * Phi shapes on row-split shards, run forward_layer over the whole batch (int8 matrix-core GEMMs,
+ * *new_pos = curr_pos + n.  The supported model shapes (Q8_0 / Q4_0; Llama / Phi heads, Gemma-2) on
+ * one GPU and on row-split shards run forward_layer over the whole batch (int8 matrix-core GEMMs,
  * transformer.rs:388-657 with sl = n; row shards: two all-gathers of quantised token-batch blocks
- * per layer); other shapes go token by token through the decode kernels.  Same values either way.
+ * per layer, four when wo / w2 are split too); other shapes (f32 files, other geometries) go token
+ * by token through the decode kernels.  Same values either way.
  * One documented deviation from the reference: n > 1 on a Q4_0 file (INTEGRATION.md
  * "Deviations": the reference multiplies token j with token 2j's nibbles; this computes the
  * token-by-token result). */

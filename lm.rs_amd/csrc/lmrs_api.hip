@@ -81,7 +81,7 @@ struct lmrs_ctx {
     bool pf_ready = false;                                 // every prefill buffer above is allocated
     // batched prefill on row shards (plan "tp", Q8_0): the gathered blocks of a token batch - per shard [n_tok x slice int8 | n_tok x slice / 128 scales],
     // pfb_att / pfb_h bytes apart; inside the peer-to-peer arena when that is the transport (peers write them), ordinary memory for RCCL
-    char *pfx_att = nullptr, *pfx_h = nullptr; size_t pfb_att = 0, pfb_h = 0; bool pfx_owned = false;
+    char *pfx_att = nullptr, *pfx_h = nullptr, *pfx_x = nullptr; size_t pfb_att = 0, pfb_h = 0, pfb_x = 0; bool pfx_owned = false;   // pfx_x: the split-out plan's f32 slices of wo / w2's output
     bool tp_prefill = false;                               // decided ONCE, at create (prefill_tp_shapes_ok: shapes and LMRS_NO_BATCHED_PREFILL) - where the blocks live follows from it
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -138,13 +138,19 @@ __global__ void stall_kernel(long long ticks) { const long long t0 = wall_clock6
 size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 constexpr int kPrefillTokens = 512;            // tokens per pass of the batched forward_layer (fill_kv_cache, the prompt of generate_greedy)
-// Batched prefill on ROW SHARDS (plan "tp"): the configurations it is built for - Q8_0 with whole 128-groups per shard (the quantised
-// exchange payload of the decode step), wo / w2 replicated, Llama / Phi head sizes; everything else feeds its tokens one by one.
+// Batched prefill on ROW SHARDS (plan "tp"): the configurations it is built for - Q8_0 and Q4_0 with whole 128-groups of att_out / h per shard
+// (a shard quantises ITS slice of every token's vector: bit for bit the groups of the gathered vector), wo / w2 replicated or split too (the
+// split-out plan: two more all-gathers per layer, of f32 row slices), Llama / Phi head sizes and Gemma-2 (round 6: Q4_0, Gemma-2 and the split-out
+// plan too); everything else feeds its tokens one by one.
 bool prefill_tp_shapes_ok(const lmrs_ctx* c) {
     const lmrs_args& a = c->args;
-    if (!c->qpay || !c->rep_out || c->cls_only || a.model_type == LMRS_GEMMA || c->no_batched_prefill) return false;
+    if (c->world < 1 || c->cls_only || c->f32 || c->no_batched_prefill) return false;
+    if (!c->rep_out && c->dim_l % 16) return false;                      // (the split-out plan: wo / w2 rows split too - their slices are whole GEMM row tiles' worth)
+    if (a.q_type != LMRS_Q8_0 && a.q_type != LMRS_Q4_0) return false;
+    if (c->att_dim % 128 || c->hid_l % 128) return false;
     if (!rows_prologue_supported((int)a.dim)) return false;
-    if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
+    if (a.model_type == LMRS_GEMMA) { if (a.head_size != 256 || a.dim != 2304) return false; }
+    else if (a.head_size != 64 && a.head_size != 96 && a.head_size != 128) return false;
     return (c->att_dim + 2 * c->kv_dim) % 16 == 0 && c->kv_dim % 4 == 0 && a.dim % 16 == 0 && c->att_full % 128 == 0 && a.hidden_dim % 128 == 0;
 }
 // bytes of one shard's block for a slice of n_l values per token: [kPrefillTokens x n_l int8 | kPrefillTokens x n_l / 128 f32]
@@ -896,7 +902,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     need(kMaxArgmaxParts * 4); need(kMaxArgmaxParts * 4); need(W * 2 * kMaxArgmaxParts * 4);
     // quantised exchange payloads (Q8_0, whole 128-groups per shard): one padded block per shard
     c->qpay = sharded && !cls_only && !c->q4 && att_l % 128 == 0 && hid_l % 128 == 0 && !getenv("LMRS_SHARD_F32_PAYLOAD");
-    c->tp_prefill = prefill_tp_shapes_ok(c);
+    c->tp_prefill = sharded && prefill_tp_shapes_ok(c);
     c->blk_att = pad256(att_l + att_l / 32); c->blk_h = pad256(hid_l + hid_l / 32);
     need(W * c->blk_att); need(W * c->blk_h);
     need(((size_t)a.seq_len + 8) * 4); need(sizeof(DevState));
@@ -973,16 +979,16 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
         auto xneed = [&](size_t b) { const size_t o = xo; xo += pad256(b); return o; };
         const size_t o_att = xneed(att * 4), o_h = xneed(hid * 4), o_tmp = xneed(dim * 4), o_logits = xneed(V * 4), o_part = xneed(2 * W * 2 * kMaxArgmaxParts * 4),
                      o_gqa = xneed(W * c->blk_att), o_gqh = xneed(W * c->blk_h), o_flags = xneed((size_t)kMaxExchangeSlots * kMaxWorld * 4), o_seq = xneed((size_t)kMaxExchangeSlots * 4), o_err = xneed(256);
-        const bool tpb = c->tp_prefill;                       // token-batch blocks of the batched prefill (two buffers: see prefill_layers_tp)
-        c->pfb_att = prefill_tp_block(att_l); c->pfb_h = prefill_tp_block(hid_l);
-        const size_t o_pfa = tpb ? xneed(W * c->pfb_att) : 0, o_pfh = tpb ? xneed(W * c->pfb_h) : 0;
+        const bool tpb = c->tp_prefill;                       // token-batch blocks of the batched prefill (two buffers: see prefill_layers)
+        c->pfb_att = prefill_tp_block(att_l); c->pfb_h = prefill_tp_block(hid_l); c->pfb_x = pad256((size_t)kPrefillTokens * dim_l * 4);
+        const size_t o_pfa = tpb ? xneed(W * c->pfb_att) : 0, o_pfh = tpb ? xneed(W * c->pfb_h) : 0, o_pfx = tpb && !rep_out ? xneed(W * c->pfb_x) : 0;
         HCK(hipExtMallocWithFlags(reinterpret_cast<void**>(&c->xarena), xo, hipDeviceMallocFinegrained));
         c->xarena_bytes = xo;
         HCK(hipMemset(c->xarena, 0, xo));
         c->att_out = reinterpret_cast<float*>(c->xarena + o_att); c->h = reinterpret_cast<float*>(c->xarena + o_h); c->tmp = reinterpret_cast<float*>(c->xarena + o_tmp);
         c->logits = reinterpret_cast<float*>(c->xarena + o_logits); c->part = reinterpret_cast<float*>(c->xarena + o_part);
         c->gq_att = c->xarena + o_gqa; c->gq_h = c->xarena + o_gqh;
-        if (tpb) { c->pfx_att = c->xarena + o_pfa; c->pfx_h = c->xarena + o_pfh; }
+        if (tpb) { c->pfx_att = c->xarena + o_pfa; c->pfx_h = c->xarena + o_pfh; if (!rep_out) c->pfx_x = c->xarena + o_pfx; }
         c->xflags = reinterpret_cast<unsigned*>(c->xarena + o_flags); c->xseq = reinterpret_cast<unsigned*>(c->xarena + o_seq); c->xerr = reinterpret_cast<int*>(c->xarena + o_err);
         c->peer_base[rank] = c->xarena;
         if (cls_only) {   // no peer ever writes the layers' activations: they belong in ordinary (L2-cached) memory; only the partials and logits are exchanged
@@ -1101,7 +1107,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : c->g_multi) if (g) (void)hipGraphExecDestroy(g);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
-    if (c->pfx_owned) { if (c->pfx_att) (void)hipFree(c->pfx_att); if (c->pfx_h) (void)hipFree(c->pfx_h); }
+    if (c->pfx_owned) { if (c->pfx_att) (void)hipFree(c->pfx_att); if (c->pfx_h) (void)hipFree(c->pfx_h); if (c->pfx_x) (void)hipFree(c->pfx_x); }
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) (void)hipHostFree(c->h_logits);
     if (c->samp_keys) (void)hipFree(c->samp_keys);
@@ -1305,13 +1311,14 @@ static int prefill_alloc(lmrs_ctx* c) {
     const lmrs_args& a = c->args;
     const size_t B = kPrefillTokens, wide = std::max<size_t>(std::max<size_t>(a.dim, a.hidden_dim), (size_t)std::max(c->att_dim, c->att_full));
     const bool own_blocks = c->tp_prefill && c->comm && !c->pfx_att;      // (peer-to-peer shards: the blocks are part of the exchange arena, laid out at create)
-    if (own_blocks) { c->pfb_att = prefill_tp_block((size_t)c->att_dim); c->pfb_h = prefill_tp_block((size_t)c->hid_l); c->pfx_owned = true; }
+    if (own_blocks) { c->pfb_att = prefill_tp_block((size_t)c->att_dim); c->pfb_h = prefill_tp_block((size_t)c->hid_l); c->pfb_x = pad256((size_t)kPrefillTokens * c->dim_l * 4); c->pfx_owned = true; }
     struct Want { void** p; size_t bytes; } want[] = {
         {reinterpret_cast<void**>(&c->pf_x), B * a.dim * 4}, {reinterpret_cast<void**>(&c->pf_q), B * c->att_dim * 4},
         {reinterpret_cast<void**>(&c->pf_k), B * c->kv_dim * 4}, {reinterpret_cast<void**>(&c->pf_ao), B * c->att_dim * 4},
         {reinterpret_cast<void**>(&c->pf_h), B * a.hidden_dim * 4}, {reinterpret_cast<void**>(&c->pf_xq), B * wide},
         {reinterpret_cast<void**>(&c->pf_xs), B * (wide / 128) * 4}, {reinterpret_cast<void**>(&c->pf_t), a.model_type == LMRS_GEMMA ? B * a.dim * 4 : 0},
-        {reinterpret_cast<void**>(&c->pfx_att), own_blocks ? c->world * c->pfb_att : 0}, {reinterpret_cast<void**>(&c->pfx_h), own_blocks ? c->world * c->pfb_h : 0}};
+        {reinterpret_cast<void**>(&c->pfx_att), own_blocks ? c->world * c->pfb_att : 0}, {reinterpret_cast<void**>(&c->pfx_h), own_blocks ? c->world * c->pfb_h : 0},
+        {reinterpret_cast<void**>(&c->pfx_x), own_blocks && !c->rep_out ? c->world * c->pfb_x : 0}};
     for (const Want& w : want) {
         if (!w.bytes || *w.p) continue;
         const hipError_t e = hipMalloc(w.p, w.bytes);
@@ -1349,11 +1356,44 @@ static int prefill_attention(lmrs_ctx* c, AttnArgs& t, int m, int p0) {
 // forward_layer(sl = m) for every layer over tokens at positions p0 .. p0+m-1 whose embeddings sit in c->pf_x.
 // Gemma: the branch outputs go to pf_t and "x += rmsnorm(branch)" (transformer.rs:563-568, 643-650) is folded into the
 // per-token prologue of the next GEMM (mode 2), as in the decode path; the last one is applied at the end.
+// On ROW SHARDS (plan "tp"; prefill_tp_shapes_ok) every shard runs the GEMMs of its own rows over the token batch - its heads' q / k / v rows and
+// attention, its gate / up pairs - and wo / w2 whole (replicated rows), so two exchanges per layer, as in the decode step: each shard quantises ITS
+// slice of every token's att_out / h (whole 128-groups: bit for bit the groups of the gathered vector; Q4_0: the int8 (q - 8) octets the batched
+// matmul_q4 reads), the blocks are all-gathered (RCCL, or the push transport's wide copy) and laid out as the next GEMM's activation operand.  The att
+// and h blocks are TWO buffers: a peer can only write block A of layer l + 1 after it has seen this shard's flag of exchange H of layer l, which
+// this shard raises after it has consumed A of layer l (stream order) - and the other way round.
+static bool row_sharded(const lmrs_ctx* c);
 static int prefill_layers(lmrs_ctx* c, int m, int p0) {
     const lmrs_args& a = c->args;
-    const int dim = (int)a.dim, hid = (int)a.hidden_dim, att = c->att_dim, kv = c->kv_dim, q4 = c->q4;
+    const bool tp = row_sharded(c);
+    const int dim = (int)a.dim, hid = (int)a.hidden_dim, att = c->att_dim, kv = c->kv_dim, hs = (int)a.head_size, q4 = c->q4, W = c->world;
+    const int att_full = tp ? c->att_full : att, hid_l = tp ? c->hid_l : hid;
     const bool gemma = a.model_type == LMRS_GEMMA;
     const float eps = a.rms_norm_eps;
+    auto all_gather = [&](const float* mine, int n_l, char* blocks, size_t cap) -> int {          // mine: [m][n_l] f32 -> pf_xq / pf_xs [m][W * n_l]
+        const size_t s_off = (size_t)m * n_l, bytes = s_off + (size_t)m * (n_l / 128) * 4, stride = pad256(bytes);
+        if (stride > cap) return fail("prefill block overflow");
+        char* blk = blocks + (size_t)c->rank * stride;
+        HIP_OK(launch_quantize_rows(mine, n_l, m, q4, reinterpret_cast<int8_t*>(blk), reinterpret_cast<float*>(blk + s_off), c->stream));
+        ExchangeDesc e{blocks, bytes, stride, nullptr, 0}; e.wide = true;
+        if (enqueue_exchange(c, e)) return -1;
+        HIP_OK(launch_gather_rows(blocks, stride, s_off, W, n_l, m, c->pf_xq, c->pf_xs, c->stream));
+        return 0;
+    };
+    // wo / w2 (g.wq, g.ws, g.n set by the caller): x += ... (Gemma: the branch buffer pf_t).  All rows on this shard, or - the split-out plan - its dim_l
+    // rows into its block of pfx_x, an all-gather of the f32 slices, and the same single addition per element from the gathered blocks
+    auto out_rows = [&](GemmArgs& g) -> int {
+        float* dst = gemma ? c->pf_t : c->pf_x;
+        if (!tp || c->rep_out) { g.o = dim; g.out = dst; HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream)); return 0; }
+        const size_t bytes = (size_t)m * c->dim_l * 4, stride = pad256(bytes);
+        if (stride > c->pfb_x || !c->pfx_x) return fail("prefill block overflow");
+        g.o = c->dim_l; g.out = reinterpret_cast<float*>(c->pfx_x + (size_t)c->rank * stride);
+        HIP_OK(launch_gemm_q8(g, EPI_STORE, c->stream));
+        ExchangeDesc e{c->pfx_x, bytes, stride, nullptr, 0}; e.wide = true;
+        if (enqueue_exchange(c, e)) return -1;
+        HIP_OK(launch_scatter_rows(c->pfx_x, stride, W, c->dim_l, m, dst, gemma ? 0 : 1, c->stream));
+        return 0;
+    };
     for (uint32_t l = 0; l < a.n_layers; ++l) {
         const DevLayer& L = c->layers[l];
         GemmArgs g{};
@@ -1364,22 +1404,26 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
         g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
         HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
-        // RoPE, keys into the cache; attention                                         (:443-544)
+        // RoPE, keys into the cache; attention (this shard's heads)                    (:443-544)
         AttnArgs t{};
         t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
-        t.n_heads = (int)a.n_heads; t.n_kv_heads = (int)a.n_kv_heads; t.head_size = (int)a.head_size; t.seq_len = (int)a.seq_len; t.layer = (int)l;
+        t.n_heads = att / hs; t.n_kv_heads = kv / hs; t.head_size = hs; t.seq_len = (int)a.seq_len; t.layer = (int)l;
         t.gemma = gemma; t.st = c->st;
         if (prefill_attention(c, t, m, p0)) return -1;
         // quantize | Wo | x += ... (Gemma: -> pf_t)                                     (:550-576)
-        HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, att, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.wo; g.ws = L.so; g.n = att; g.o = dim; g.out = gemma ? c->pf_t : c->pf_x;
-        HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream));
+        if (tp) { if (all_gather(c->pf_ao, att, c->pfx_att, c->pfb_att)) return -1; }
+        else HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, att, m, c->pf_xq, c->pf_xs, c->stream));
+        g.wq = L.wo; g.ws = L.so; g.n = att_full;
+        if (out_rows(g)) return -1;
         // [x += rmsnorm(attention out)] rmsnorm + quantize | W1, W3 | act(gate) * up  (:578-624)
         if (gemma) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_pre_ffn, c->pf_t, L.rms_post_att, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
         else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, nullptr, nullptr, eps, 0, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * hid; g.out = c->pf_h;
+        g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * hid_l; g.out = c->pf_h;
         // quantize | W2 | x += ... (Gemma: -> pf_t)                                     (:630-654)
-        if (!c->no_fused_hq && gemm_q8_hq_fused(dim, 2 * hid, m, q4 != 0)) {
+        if (tp) {
+            HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
+            if (all_gather(c->pf_h, hid_l, c->pfx_h, c->pfb_h)) return -1;
+        } else if (!c->no_fused_hq && gemm_q8_hq_fused(dim, 2 * hid, m, q4 != 0)) {
             // (the quantiser of h in w1/w3's epilogue: int8 rows + scales in the buffer the f32 rows would have taken)
             g.hq = reinterpret_cast<int8_t*>(c->pf_h); g.hs = reinterpret_cast<float*>(reinterpret_cast<char*>(c->pf_h) + (size_t)kPrefillTokens * hid);
             HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU_Q : EPI_SWIGLU_Q, c->stream));
@@ -1388,62 +1432,17 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
             HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
             HIP_OK(launch_rows_prologue(c->pf_h, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, hid, m, c->pf_xq, c->pf_xs, c->stream));
         }
-        g.wq = L.w2; g.ws = L.s2; g.n = hid; g.o = dim; g.out = gemma ? c->pf_t : c->pf_x;
-        HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream));
+        g.wq = L.w2; g.ws = L.s2; g.n = hid;
+        if (out_rows(g)) return -1;
     }
     if (gemma) HIP_OK(launch_rows_addnorm(c->pf_x, c->pf_t, c->layers[a.n_layers - 1].rms_post_ffn, eps, dim, m, c->stream));
-    return 0;
-}
-
-// The same on ROW SHARDS (plan "tp"; prefill_tp_shapes_ok): every shard runs the GEMMs of its own rows over the token batch - its heads' q / k / v
-// rows and attention, its gate / up pairs - and wo / w2 whole (replicated rows), so two exchanges per layer, as in the decode step: each shard
-// quantises ITS slice of every token's att_out / h (whole 128-groups: bit for bit the groups of the gathered vector), the blocks are
-// all-gathered (RCCL, or the push transport's wide copy) and laid out as the next GEMM's activation operand.  The att and h blocks are TWO
-// buffers: a peer can only write block A of layer l + 1 after it has seen this shard's flag of exchange H of layer l, which this shard
-// raises after it has consumed A of layer l (stream order) - and the other way round.
-static int prefill_layers_tp(lmrs_ctx* c, int m, int p0) {
-    const lmrs_args& a = c->args;
-    const int dim = (int)a.dim, hid = (int)a.hidden_dim, att = c->att_dim, kv = c->kv_dim, hs = (int)a.head_size, W = c->world;
-    const float eps = a.rms_norm_eps;
-    auto all_gather = [&](const float* mine, int n_l, char* blocks, size_t cap) -> int {          // mine: [m][n_l] f32 -> pf_xq / pf_xs [m][W * n_l]
-        const size_t s_off = (size_t)m * n_l, bytes = s_off + (size_t)m * (n_l / 128) * 4, stride = pad256(bytes);
-        if (stride > cap) return fail("prefill block overflow");
-        char* blk = blocks + (size_t)c->rank * stride;
-        HIP_OK(launch_quantize_rows(mine, n_l, m, reinterpret_cast<int8_t*>(blk), reinterpret_cast<float*>(blk + s_off), c->stream));
-        ExchangeDesc e{blocks, bytes, stride, nullptr, 0}; e.wide = true;
-        if (enqueue_exchange(c, e)) return -1;
-        HIP_OK(launch_gather_rows(blocks, stride, s_off, W, n_l, m, c->pf_xq, c->pf_xs, c->stream));
-        return 0;
-    };
-    for (uint32_t l = 0; l < a.n_layers; ++l) {
-        const DevLayer& L = c->layers[l];
-        GemmArgs g{};
-        g.xq = c->pf_xq; g.xs = c->pf_xs; g.n_tok = m; g.q4 = 0;
-        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, nullptr, nullptr, eps, 0, 1, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
-        g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
-        HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
-        AttnArgs t{};
-        t.q = c->pf_q; t.k_raw = nullptr; t.k_cache = c->k_cache; t.v_cache = c->v_cache; t.rope = c->rope; t.out = c->pf_ao;
-        t.n_heads = att / hs; t.n_kv_heads = kv / hs; t.head_size = hs; t.seq_len = (int)a.seq_len; t.layer = (int)l; t.gemma = false; t.st = c->st;
-        if (prefill_attention(c, t, m, p0)) return -1;
-        if (all_gather(c->pf_ao, att, c->pfx_att, c->pfb_att)) return -1;
-        g.wq = L.wo; g.ws = L.so; g.n = c->att_full; g.o = dim; g.out = c->pf_x;
-        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
-        HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, nullptr, nullptr, eps, 0, 1, 0, dim, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * c->hid_l; g.out = c->pf_h;
-        HIP_OK(launch_gemm_q8(g, EPI_SWIGLU, c->stream));
-        if (all_gather(c->pf_h, c->hid_l, c->pfx_h, c->pfb_h)) return -1;
-        g.wq = L.w2; g.ws = L.s2; g.n = hid; g.o = dim; g.out = c->pf_x;
-        HIP_OK(launch_gemm_q8(g, EPI_RESID, c->stream));
-    }
     return 0;
 }
 // (a communicator of ONE rank counts as a row-sharded context - the RCCL branch of the batched path can then run, and be tested, on a one-GPU box)
 static bool row_sharded(const lmrs_ctx* c) { return (c->world > 1 || c->comm) && !c->cls_only; }
 static bool prefill_tp_ok(const lmrs_ctx* c) { return c->tp_prefill && row_sharded(c) && (c->comm || (c->p2p && c->p2p_ready && c->pfx_att)); }
 static int prefill_pass(lmrs_ctx* c, int m, int p0) {
-    if (row_sharded(c)) { c->ex_slot = 0; return prefill_layers_tp(c, m, p0); }
+    if (row_sharded(c)) c->ex_slot = 0;
     return prefill_layers(c, m, p0);
 }
 

@@ -142,8 +142,9 @@ int sample_sort_min_n();
 // thin kernels over the same device functions, for the lmrs_op_* unit-parity entry points
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st);
 // batched prefill on row shards (Q8_0): this shard's slices of n_tok tokens quantised into its exchange block; the gathered blocks as a GEMM operand
-hipError_t launch_quantize_rows(const float* x, int n, int n_tok, int8_t* q, float* s, hipStream_t st);
+hipError_t launch_quantize_rows(const float* x, int n, int n_tok, int q4, int8_t* q, float* s, hipStream_t st);
 hipError_t launch_gather_rows(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int n_tok, int8_t* xq, float* xs, hipStream_t st);
+hipError_t launch_scatter_rows(const char* blocks, size_t blk_stride, int world, int n_l, int n_tok, float* dst, int add, hipStream_t st);
 hipError_t launch_rmsnorm(const float* x, const float* w, float* o, int n, float eps, int add_unit, hipStream_t st);
 hipError_t launch_softmax(float* x, int n, hipStream_t st);
 hipError_t launch_expf(const float* x, float* y, size_t n, hipStream_t st);

@@ -3141,7 +3141,9 @@ __global__ __launch_bounds__(kBlock) void quantize_kernel(const float* x, void* 
 }
 
 // Batched prefill on row shards: token t's slice of n values (whole 128-groups) -> [n int8] at q + t * n, its scales at s + t * (n / 128);
-// the arithmetic of quantize_to_lds, i.e. bit for bit what quantising the gathered vector gives for these groups.
+// the arithmetic of quantize_to_lds, i.e. bit for bit what quantising the gathered vector gives for these groups.  Q4: the reference's Q4_0
+// activation quantiser, the values (q - 8) as int8, de-interleaved within every 8 elements - what the batched matmul_q4 reads (rows_prologue_kernel).
+template <bool Q4>
 __global__ __launch_bounds__(kBlock) void quantize_rows_kernel(const float* x, int8_t* q, float* s, int n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int8_t* xq = reinterpret_cast<int8_t*>(smem);
@@ -3149,12 +3151,19 @@ __global__ __launch_bounds__(kBlock) void quantize_rows_kernel(const float* x, i
     const size_t t = blockIdx.x;
     float4 v[kMaxP];
     load_vec(v, x + t * n, n);
-    quantize_to_lds<false, kMaxP>(v, n, xq, xs, q + t * n, s + t * (n / kGS));
+    if constexpr (!Q4) quantize_to_lds<false, kMaxP>(v, n, xq, xs, q + t * n, s + t * (n / kGS));
+    else {
+        quantize_to_lds<true, kMaxP>(v, n, xq, xs, nullptr, nullptr);
+        lds_barrier();
+        for (int e = threadIdx.x * 16; e < n; e += kBlock * 16) *reinterpret_cast<int4*>(q + t * n + e) = *reinterpret_cast<const int4*>(xq + e);   // (n is a multiple of 128)
+        for (int g = threadIdx.x; g < n / kGS; g += kBlock) s[t * (n / kGS) + g] = xs[g];
+    }
 }
-hipError_t launch_quantize_rows(const float* x, int n, int n_tok, int8_t* q, float* s, hipStream_t st) {
+hipError_t launch_quantize_rows(const float* x, int n, int n_tok, int q4, int8_t* q, float* s, hipStream_t st) {
     if (n % kGS || n > kMaxP * 1024 || n_tok <= 0) return hipErrorInvalidValue;
     const size_t smem = ((n + 15) & ~15) + (size_t)(n / kGS + 4) * 4;
-    hipLaunchKernelGGL(quantize_rows_kernel, dim3(n_tok), dim3(kBlock), smem, st, x, q, s, n);
+    if (q4) hipLaunchKernelGGL(quantize_rows_kernel<true>, dim3(n_tok), dim3(kBlock), smem, st, x, q, s, n);
+    else hipLaunchKernelGGL(quantize_rows_kernel<false>, dim3(n_tok), dim3(kBlock), smem, st, x, q, s, n);
     return hipGetLastError();
 }
 // ... and the gathered blocks of all shards ([w]: n_tok x n_l int8, then at s_off n_tok x n_l / 128 scales) as the activation operand of the
@@ -3174,6 +3183,27 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const char* blocks,
 hipError_t launch_gather_rows(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int n_tok, int8_t* xq, float* xs, hipStream_t st) {
     if (n_l % kGS || s_off % 16 || blk_stride % 16) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(n_tok), dim3(kBlock), 0, st, blocks, blk_stride, s_off, world, n_l, xq, xs);
+    return hipGetLastError();
+}
+
+// Row shards that split wo / w2 too (the split-out plan): every shard's [n_tok x n_l] f32 slice of the projection's output, gathered, becomes columns
+// w * n_l .. of the full rows: dst[t][w * n_l + j] = blk_w[t][j] (store: Gemma's branch buffer) or dst + blk (the residual add, transformer.rs:574 / :652 -
+// the same single addition per element as the GEMM's own epilogue).  One workgroup per token; 16 bytes per lane.
+__global__ __launch_bounds__(kBlock) void scatter_rows_kernel(const char* blocks, size_t blk_stride, int world, int n_l, float* dst, int add) {
+    const size_t t = blockIdx.x;
+    const int n = world * n_l;
+    for (int e = threadIdx.x * 4; e < n; e += kBlock * 4) {
+        const int w = e / n_l, j = e - w * n_l;
+        typedef float f32x4s __attribute__((ext_vector_type(4)));
+        const f32x4s v = __builtin_nontemporal_load(reinterpret_cast<const f32x4s*>(blocks + (size_t)w * blk_stride) + (t * n_l + j) / 4);
+        float4* d = reinterpret_cast<float4*>(dst + t * n + e);
+        if (add) { float4 x = *d; x.x = x.x + v.x; x.y = x.y + v.y; x.z = x.z + v.z; x.w = x.w + v.w; *d = x; }
+        else *d = make_float4(v.x, v.y, v.z, v.w);
+    }
+}
+hipError_t launch_scatter_rows(const char* blocks, size_t blk_stride, int world, int n_l, int n_tok, float* dst, int add, hipStream_t st) {
+    if (n_l % 4 || blk_stride % 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(n_tok), dim3(kBlock), 0, st, blocks, blk_stride, world, n_l, dst, add);
     return hipGetLastError();
 }
 

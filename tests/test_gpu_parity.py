@@ -829,24 +829,28 @@ def _p2p_rank(rank, world, img_path, cfg, env, q_in, q_out, n_fill=6, n_prompt=3
         q_out.put((rank, "error", traceback.format_exc()))
 
 
-@pytest.mark.parametrize("cfg,world,plan,n_fill,n_prompt", [
-    ("mini-llama", 2, "tp", 6, 3), ("mini-gemma", 2, "tp", 6, 3), ("mini-llama3b", 4, "tp", 6, 3), ("mini-llama", 4, "cls", 6, 3), ("mini-gemma", 2, "cls", 6, 3),
-    ("mini-llama", 2, "tp-tokenwise", 6, 3),          # LMRS_NO_BATCHED_PREFILL: the row shards' token-by-token fill_kv_cache
-    ("mini-llama", 2, "tp", 70, 12), ("mini-llama3b", 4, "tp", 70, 12), ("mini-phi", 2, "tp", 40, 9)])     # batched forward_layer on row shards, block attention, batched prompt
-def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan, n_fill, n_prompt):
+@pytest.mark.parametrize("cfg,world,plan,n_fill,n_prompt,q", [
+    ("mini-llama", 2, "tp", 6, 3, S.Q8_0), ("mini-gemma", 2, "tp", 6, 3, S.Q8_0), ("mini-llama3b", 4, "tp", 6, 3, S.Q8_0), ("mini-llama", 4, "cls", 6, 3, S.Q8_0),
+    ("mini-gemma", 2, "cls", 6, 3, S.Q8_0),
+    ("mini-llama", 2, "tp-tokenwise", 6, 3, S.Q8_0),          # LMRS_NO_BATCHED_PREFILL: the row shards' token-by-token fill_kv_cache
+    ("mini-llama", 2, "tp", 70, 12, S.Q8_0), ("mini-llama3b", 4, "tp", 70, 12, S.Q8_0), ("mini-phi", 2, "tp", 40, 9, S.Q8_0),     # batched forward_layer on row shards, block attention, batched prompt
+    ("mini-gemma", 2, "tp", 70, 12, S.Q8_0), ("mini-llama", 2, "tp", 70, 12, S.Q4_0), ("mini-gemma", 2, "tp", 70, 12, S.Q4_0),    # round 6: Gemma-2 and Q4_0 on row shards
+    ("mini-llama", 2, "tp-splitout", 70, 12, S.Q8_0), ("mini-llama3b", 4, "tp-splitout", 70, 12, S.Q8_0), ("mini-gemma", 2, "tp-splitout", 70, 12, S.Q4_0)])   # ... and wo / w2 split too
+def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan, n_fill, n_prompt, q):
     """The multi-GPU launch shape on a one-GPU box: `world` PROCESSES, one shard each (here all on device 0), exchange arenas opened
     through IPC handles, every exchange a push kernel that really waits for the other process's flag.  fill_kv_cache on the shards,
     greedy decoding across the split-attention switch, full logits on every rank - all bit-equal to the CPU path.  plan "tp": the
     layers' matrices row-split (exchanges inside every layer); "cls": whole layers on every shard, the classifier split (one exchange
-    per token).  Plan "tp" with Q8_0 Llama / Phi shapes runs fill_kv_cache and the prompt of generate_greedy as forward_layer over the token
-    batch on every shard (prefill_layers_tp: two all-gathers of quantised token-batch blocks per layer)."""
+    per token).  Plan "tp" (Q8_0 and Q4_0; Llama / Phi shapes and Gemma-2) runs fill_kv_cache and the prompt of generate_greedy as
+    forward_layer over the token batch on every shard (prefill_layers: two all-gathers of quantised token-batch blocks per layer)."""
     import multiprocessing as mp
-    img = S.build_image(cfg, S.Q8_0, seed=43)
+    img = S.build_image(cfg, q, seed=43)
     path = str(tmp_path / "m.lmrs"); img.tofile(path)
     ctx = mp.get_context("spawn")
     q_out = ctx.Queue(); q_in = [ctx.Queue() for _ in range(world)]
     env = {"LMRS_ATT_SPLIT_POS": "16", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "LMRS_P2P_TIMEOUT_MS": "1500", "LMRS_SHARD_PLAN": plan.split("-")[0]}
     if plan.endswith("tokenwise"): env["LMRS_NO_BATCHED_PREFILL"] = "1"
+    if plan.endswith("splitout"): env["LMRS_SHARD_SPLIT_OUT"] = "1"
     procs = [ctx.Process(target=_p2p_rank, args=(r, world, path, cfg, env, q_in[r], q_out, n_fill, n_prompt)) for r in range(world)]
     for p in procs: p.start()
     try:
@@ -873,7 +877,7 @@ def test_peer_to_peer_shards_in_separate_processes(L, tmp_path, cfg, world, plan
     for r in range(world):
         emb, newp, toks, lg, graph, batched = res[r]
         assert newp == p_ref
-        assert batched == (plan == "cls" or (plan == "tp" and cfg != "mini-gemma")), f"rank {r}: fill_kv_cache took the {'batched' if batched else 'token-by-token'} path"
+        assert batched == (plan in ("cls", "tp", "tp-splitout")), f"rank {r}: fill_kv_cache took the {'batched' if batched else 'token-by-token'} path"
         assert_bit_equal(emb, e_ref, f"rank {r}: embeddings after the sharded fill_kv_cache")
         assert (toks == t_ref).all(), (r, toks, t_ref)
         assert_bit_equal(lg, l_ref, f"rank {r}: logits")
@@ -958,24 +962,25 @@ def test_bench_fallback_is_taken_by_all_ranks_together(tmp_path):
     assert d["parity"]["tokens_equal"] and d["n_gpus"] == 2
 
 
-def test_rccl_path_with_one_rank(L):
+@pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q8_0), ("mini-gemma", S.Q4_0)])
+def test_rccl_path_with_one_rank(L, cfg, q):
     """The RCCL code path (communicator, all-gathers between the segments, graph capture) with world = 1."""
-    img = S.build_image("mini-llama", S.Q8_0, seed=32)
+    img = S.build_image(cfg, q, seed=32)
     m = L.Transformer(img, rank=0, world=1, unique_id=L.comm_unique_id())
     orc = O.Oracle(img)
-    prompt = S.prompt_tokens("mini-llama", 4, 32)
+    prompt = S.prompt_tokens(cfg, 4, 32)
     assert (m.generate_greedy(prompt, 8) == orc.generate_greedy(prompt, 8)).all()
     o2 = O.Oracle(img)
     for pos, t in enumerate(prompt):
         assert_bit_equal(m.forward(int(t), pos), o2.forward(int(t), pos), f"rccl world=1 logits at pos {pos}")
     # the batched forward_layer of a row-sharded context over RCCL (prefill_layers_tp: quantised token-batch blocks, ncclAllGather in place, gather
     # kernel) - one rank is all a one-GPU box can give RCCL, but it is the same code: fill_kv_cache of 70 tokens, then a 12-token prompt
-    toks = S.prompt_tokens("mini-llama", 70, 33)
+    toks = S.prompt_tokens(cfg, 70, 33)
     a = m.get_embeddings(toks); b = o2.get_embeddings(toks)
     assert m.fill_kv_cache(a, 4) == o2.fill_kv_cache(b, 4) == 74
     assert m.last_fill_ms() > 0                                             # (only the batched path records its device time)
     assert_bit_equal(a, b, "rccl world=1: residual stream after the batched layers")
-    p2 = S.prompt_tokens("mini-llama", 12, 34)
+    p2 = S.prompt_tokens(cfg, 12, 34)
     assert (m.generate_greedy(p2, 8, start_pos=74) == o2.generate_greedy(p2, 8, start_pos=74)).all()
 
 

@@ -962,9 +962,11 @@ def test_bench_fallback_is_taken_by_all_ranks_together(tmp_path):
     assert d["parity"]["tokens_equal"] and d["n_gpus"] == 2
 
 
-@pytest.mark.parametrize("cfg,q", [("mini-llama", S.Q8_0), ("mini-gemma", S.Q4_0)])
-def test_rccl_path_with_one_rank(L, cfg, q):
-    """The RCCL code path (communicator, all-gathers between the segments, graph capture) with world = 1."""
+@pytest.mark.parametrize("cfg,q,split_out", [("mini-llama", S.Q8_0, False), ("mini-gemma", S.Q4_0, False), ("mini-llama", S.Q8_0, True), ("mini-gemma", S.Q8_0, True)])
+def test_rccl_path_with_one_rank(L, monkeypatch, cfg, q, split_out):
+    """The RCCL code path (communicator, all-gathers between the segments, graph capture) with world = 1; split_out: the plan whose wo / w2
+    rows are split too (with one rank the "slice" is all rows, but the blocks, the gathers and the scatter-add are the code that runs)."""
+    if split_out: monkeypatch.setenv("LMRS_SHARD_SPLIT_OUT", "1")
     img = S.build_image(cfg, q, seed=32)
     m = L.Transformer(img, rank=0, world=1, unique_id=L.comm_unique_id())
     orc = O.Oracle(img)

@@ -149,6 +149,10 @@ def test_gemm_tile_choice_for_the_baseline_shapes():
     assert t(1024, 4096, 1154) == (256, 128, 8) and t(4096, 1024, 1154) == (128, 64, 8)
     # Gemma-2-2B Q4_0: under-filled wo / w2 on 64 x 32, the gate / up pairs on 256 x 128
     assert t(2048, 2304, 256, q4=True) == (64, 32, 4) and t(9216, 2304, 256, q4=True) == (64, 32, 4) and t(2304, 18432, 256, q4=True) == (256, 128, 8)
+    # ... round 6: at 512 tokens everything of Gemma-2-2B on 64 x 64 paired-group tiles (288 tiles of 256 x 128 would take two turns; the narrow
+    # projections' 128 x 128 tiles filled a quarter of the chip); Llama-3.2-1B Q4_0 keeps the big ring tiles for w1/w3 (exactly one turn)
+    assert t(9216, 2304, 512, q4=True) == (64, 64, 4) and t(2304, 18432, 512, q4=True) == (64, 64, 4) and t(2304, 4096, 512, q4=True) == (64, 64, 4)
+    assert t(2048, 16384, 512, q4=True) == (256, 128, 8) and t(2048, 16384, 256, q4=True) == (128, 128, 8) and t(8192, 2048, 512, q4=True) == (64, 64, 4)
     assert t(2048, 2048, 47) == (0, 0, 0)                                   # below 48 tokens: the direct kernels
     with pytest.raises(Exception): t(2000, 2048, 64)
 

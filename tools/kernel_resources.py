@@ -20,7 +20,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 OBJECTS = ["lmrs_kernels.o", "lmrs_api.o", "lmrs_vision_att.o"]
 TABLE = os.path.join(ROOT, "tests", "golden", "kernel_resources.json")
 # the kernel classes of the decode step, the batched prefill and the image tower (everything a bench line or a profile quotes)
-HOT = re.compile(r"^(?:void )?lmrs::(gemv_static_kernel|qkv_attn_kernel|gemm_q8_dma_kernel|attention_split_values_kernel|attention_split_scores_kernel|"
+HOT = re.compile(r"^(?:void )?lmrs::(gemv_static_kernel|qkv_attn_kernel|gemm_q8_dma_kernel|gemm_q4_pair_kernel|attention_split_values_kernel|attention_split_scores_kernel|"
                  r"attention_kernel|att_scores_kernel|att_scores_wide_kernel|att_softmax_kernel|att_values_kernel|vis_att_\w+|rows_\w+_kernel|sample_\w+_kernel)\b")
 
 

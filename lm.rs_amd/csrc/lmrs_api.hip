@@ -49,6 +49,7 @@ namespace {
 struct DevLayer {
     const void *wqkv, *wo, *w13, *w2;
     const float *sqkv, *so, *s13, *s2;
+    const float *sqkvT = nullptr, *soT = nullptr, *s13T = nullptr, *s2T = nullptr;    // the same scales TRANSPOSED ([group][row]) for the batched path's ring GEMMs (prefill_alloc)
     const float *rms_att, *rms_post_att, *rms_pre_ffn, *rms_post_ffn;
 };
 
@@ -86,6 +87,7 @@ struct lmrs_ctx {
     float* x2 = nullptr; bool gemma_fused = false;           // Gemma: second residual buffer; norm+add steps folded into the consuming GEMV prologues
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool no_graph = false;                         // LMRS_NO_GRAPH=1 (read at create): steps are enqueued launch by launch (profiling aid, see launch_step)
+    std::vector<float*> scales_t;                  // the layers' transposed scale copies (owned)
     bool no_batched_prefill = false;               // LMRS_NO_BATCHED_PREFILL=1 (read ONCE, at create): fill_kv_cache and prompts go token by token through the decode kernels
     bool no_fused_rope = false, no_fused_hq = false; // LMRS_NO_PREFILL_FUSION=1 (read at create; A/B aid): the batched prefill with RoPE and the h quantiser as launches of their own
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
@@ -1107,6 +1109,7 @@ extern "C" void lmrs_destroy(lmrs_ctx* c) {
     for (auto& g : c->g_step_alt) if (g) (void)hipGraphExecDestroy(g);
     for (auto& g : c->g_multi) if (g) (void)hipGraphExecDestroy(g);
     for (void* q : {(void*)c->pf_x, (void*)c->pf_q, (void*)c->pf_k, (void*)c->pf_ao, (void*)c->pf_h, (void*)c->pf_xq, (void*)c->pf_xs, (void*)c->pf_t, (void*)c->pf_att}) if (q) (void)hipFree(q);
+    for (float* q : c->scales_t) if (q) (void)hipFree(q);
     if (c->pfx_owned) { if (c->pfx_att) (void)hipFree(c->pfx_att); if (c->pfx_h) (void)hipFree(c->pfx_h); if (c->pfx_x) (void)hipFree(c->pfx_x); }
     if (c->comm) ncclCommDestroy(c->comm);
     if (c->h_logits) (void)hipHostFree(c->h_logits);
@@ -1327,6 +1330,28 @@ static int prefill_alloc(lmrs_ctx* c) {
             return fail(std::string("prefill buffers: hipMalloc: ") + hipGetErrorString(e));
         }
     }
+    // The layers' weight scales transposed, [group][row], once: a ring GEMM fetches a group's scales of 64 rows as 256 consecutive bytes instead of 4 bytes
+    // from each of 64 lines (GemmArgs::ws_ld; +1/32 of the quantised weights' bytes).  A failed allocation only means the row-major scales stay in use.
+    if (!c->f32 && c->layers.size() && !c->layers[0].sqkvT && !getenv("LMRS_NO_TRANSPOSED_SCALES")) {
+        const lmrs_args& A = c->args;
+        const bool tp = c->world > 1 || c->comm;
+        const int dim = (int)A.dim, hid = (int)A.hidden_dim, att_full = tp && !c->cls_only ? c->att_full : c->att_dim;
+        const int hid_l = tp && !c->cls_only ? c->hid_l : hid, dim_l = tp && !c->cls_only && !c->rep_out ? c->dim_l : dim;
+        bool ok = true;
+        auto tr = [&](const float* src, int rows, int groups) -> const float* {
+            if (!ok) return nullptr;
+            float* d = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&d), (size_t)rows * groups * 4) != hipSuccess) { (void)hipGetLastError(); ok = false; return nullptr; }
+            c->scales_t.push_back(d);
+            if (launch_transpose_scales(src, rows, groups, d, c->stream) != hipSuccess) { ok = false; return nullptr; }
+            return d;
+        };
+        for (DevLayer& L : c->layers) {
+            L.sqkvT = tr(L.sqkv, c->att_dim + 2 * c->kv_dim, dim / 128); L.soT = tr(L.so, dim_l, att_full / 128);
+            L.s13T = tr(L.s13, 2 * hid_l, dim / 128); L.s2T = tr(L.s2, dim_l, hid / 128);
+        }
+        if (!ok) for (DevLayer& L : c->layers) L.sqkvT = L.soT = L.s13T = L.s2T = nullptr;
+    }
     c->pf_ready = true;
     return 0;
 }
@@ -1370,6 +1395,10 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
     const int att_full = tp ? c->att_full : att, hid_l = tp ? c->hid_l : hid;
     const bool gemma = a.model_type == LMRS_GEMMA;
     const float eps = a.rms_norm_eps;
+    // scale layouts of this pass: from 48 tokens on every GEMM is a ring kernel, which takes TRANSPOSED scales ([group][row]: GemmArgs::ws_ld / xs_ld) -
+    // the weights' transposed copies (prefill_alloc) and activation scales written that way by their producers, leading dimension kPrefillTokens
+    const bool trs = m >= 48 && c->layers[0].sqkvT != nullptr;
+    const int xld = trs ? kPrefillTokens : 0;
     auto all_gather = [&](const float* mine, int n_l, char* blocks, size_t cap) -> int {          // mine: [m][n_l] f32 -> pf_xq / pf_xs [m][W * n_l]
         const size_t s_off = (size_t)m * n_l, bytes = s_off + (size_t)m * (n_l / 128) * 4, stride = pad256(bytes);
         if (stride > cap) return fail("prefill block overflow");
@@ -1377,17 +1406,17 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         HIP_OK(launch_quantize_rows(mine, n_l, m, q4, reinterpret_cast<int8_t*>(blk), reinterpret_cast<float*>(blk + s_off), c->stream));
         ExchangeDesc e{blocks, bytes, stride, nullptr, 0}; e.wide = true;
         if (enqueue_exchange(c, e)) return -1;
-        HIP_OK(launch_gather_rows(blocks, stride, s_off, W, n_l, m, c->pf_xq, c->pf_xs, c->stream));
+        HIP_OK(launch_gather_rows(blocks, stride, s_off, W, n_l, m, c->pf_xq, c->pf_xs, c->stream, xld));
         return 0;
     };
     // wo / w2 (g.wq, g.ws, g.n set by the caller): x += ... (Gemma: the branch buffer pf_t).  All rows on this shard, or - the split-out plan - its dim_l
     // rows into its block of pfx_x, an all-gather of the f32 slices, and the same single addition per element from the gathered blocks
     auto out_rows = [&](GemmArgs& g) -> int {
         float* dst = gemma ? c->pf_t : c->pf_x;
-        if (!tp || c->rep_out) { g.o = dim; g.out = dst; HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream)); return 0; }
+        if (!tp || c->rep_out) { g.o = dim; g.out = dst; if (trs) g.ws_ld = dim; HIP_OK(launch_gemm_q8(g, gemma ? EPI_STORE : EPI_RESID, c->stream)); return 0; }
         const size_t bytes = (size_t)m * c->dim_l * 4, stride = pad256(bytes);
         if (stride > c->pfb_x || !c->pfx_x) return fail("prefill block overflow");
-        g.o = c->dim_l; g.out = reinterpret_cast<float*>(c->pfx_x + (size_t)c->rank * stride);
+        g.o = c->dim_l; g.out = reinterpret_cast<float*>(c->pfx_x + (size_t)c->rank * stride); if (trs) g.ws_ld = c->dim_l;
         HIP_OK(launch_gemm_q8(g, EPI_STORE, c->stream));
         ExchangeDesc e{c->pfx_x, bytes, stride, nullptr, 0}; e.wide = true;
         if (enqueue_exchange(c, e)) return -1;
@@ -1397,11 +1426,11 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
     for (uint32_t l = 0; l < a.n_layers; ++l) {
         const DevLayer& L = c->layers[l];
         GemmArgs g{};
-        g.xq = c->pf_xq; g.xs = c->pf_xs; g.n_tok = m; g.q4 = q4;
+        g.xq = c->pf_xq; g.xs = c->pf_xs; g.n_tok = m; g.q4 = q4; g.xs_ld = xld;
         // [x += rmsnorm(previous ffn out)] rmsnorm + quantize | Wqkv | q, raw k, v rows -> cache      (transformer.rs:409-431)
-        if (gemma && l > 0) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, c->pf_t, c->layers[l - 1].rms_post_ffn, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
-        else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, nullptr, nullptr, eps, gemma, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.wqkv; g.ws = L.sqkv; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
+        if (gemma && l > 0) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, c->pf_t, c->layers[l - 1].rms_post_ffn, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream, xld));
+        else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_att, nullptr, nullptr, eps, gemma, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream, xld));
+        g.wq = L.wqkv; g.ws = trs ? L.sqkvT : L.sqkv; g.ws_ld = trs ? att + 2 * kv : 0; g.n = dim; g.o = att + 2 * kv; g.out = c->pf_q; g.k_raw = c->pf_k; g.v_cache = c->v_cache;
         g.att_dim = att; g.kv_dim = kv; g.seq_len = (int)a.seq_len; g.layer = (int)l; g.pos0 = p0;
         HIP_OK(launch_gemm_q8(g, EPI_QKV, c->stream));
         // RoPE, keys into the cache; attention (this shard's heads)                    (:443-544)
@@ -1412,13 +1441,13 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         if (prefill_attention(c, t, m, p0)) return -1;
         // quantize | Wo | x += ... (Gemma: -> pf_t)                                     (:550-576)
         if (tp) { if (all_gather(c->pf_ao, att, c->pfx_att, c->pfb_att)) return -1; }
-        else HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, att, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.wo; g.ws = L.so; g.n = att_full;
+        else HIP_OK(launch_rows_prologue(c->pf_ao, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, att, m, c->pf_xq, c->pf_xs, c->stream, xld));
+        g.wq = L.wo; g.ws = trs ? L.soT : L.so; g.n = att_full;
         if (out_rows(g)) return -1;
         // [x += rmsnorm(attention out)] rmsnorm + quantize | W1, W3 | act(gate) * up  (:578-624)
-        if (gemma) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_pre_ffn, c->pf_t, L.rms_post_att, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
-        else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, nullptr, nullptr, eps, 0, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream));
-        g.wq = L.w13; g.ws = L.s13; g.n = dim; g.o = 2 * hid_l; g.out = c->pf_h;
+        if (gemma) HIP_OK(launch_rows_prologue(c->pf_x, L.rms_pre_ffn, c->pf_t, L.rms_post_att, eps, 1, 2, q4, dim, m, c->pf_xq, c->pf_xs, c->stream, xld));
+        else HIP_OK(launch_rows_prologue(c->pf_x, L.rms_post_att, nullptr, nullptr, eps, 0, 1, q4, dim, m, c->pf_xq, c->pf_xs, c->stream, xld));
+        g.wq = L.w13; g.ws = trs ? L.s13T : L.s13; g.ws_ld = trs ? 2 * hid_l : 0; g.n = dim; g.o = 2 * hid_l; g.out = c->pf_h;
         // quantize | W2 | x += ... (Gemma: -> pf_t)                                     (:630-654)
         if (tp) {
             HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
@@ -1426,13 +1455,14 @@ static int prefill_layers(lmrs_ctx* c, int m, int p0) {
         } else if (!c->no_fused_hq && gemm_q8_hq_fused(dim, 2 * hid, m, q4 != 0)) {
             // (the quantiser of h in w1/w3's epilogue: int8 rows + scales in the buffer the f32 rows would have taken)
             g.hq = reinterpret_cast<int8_t*>(c->pf_h); g.hs = reinterpret_cast<float*>(reinterpret_cast<char*>(c->pf_h) + (size_t)kPrefillTokens * hid);
+            g.hs_ld = xld;
             HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU_Q : EPI_SWIGLU_Q, c->stream));
             g.xq = g.hq; g.xs = g.hs;
         } else {
             HIP_OK(launch_gemm_q8(g, gemma ? EPI_GELU : EPI_SWIGLU, c->stream));
-            HIP_OK(launch_rows_prologue(c->pf_h, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, hid, m, c->pf_xq, c->pf_xs, c->stream));
+            HIP_OK(launch_rows_prologue(c->pf_h, nullptr, nullptr, nullptr, 0.f, 0, 0, q4, hid, m, c->pf_xq, c->pf_xs, c->stream, xld));
         }
-        g.wq = L.w2; g.ws = L.s2; g.n = hid;
+        g.wq = L.w2; g.ws = trs ? L.s2T : L.s2; g.n = hid;
         if (out_rows(g)) return -1;
     }
     if (gemma) HIP_OK(launch_rows_addnorm(c->pf_x, c->pf_t, c->layers[a.n_layers - 1].rms_post_ffn, eps, dim, m, c->stream));

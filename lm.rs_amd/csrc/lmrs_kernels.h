@@ -143,7 +143,7 @@ int sample_sort_min_n();
 hipError_t launch_quantize(const float* x, void* q, float* s, int n, int q4, hipStream_t st);
 // batched prefill on row shards (Q8_0): this shard's slices of n_tok tokens quantised into its exchange block; the gathered blocks as a GEMM operand
 hipError_t launch_quantize_rows(const float* x, int n, int n_tok, int q4, int8_t* q, float* s, hipStream_t st);
-hipError_t launch_gather_rows(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int n_tok, int8_t* xq, float* xs, hipStream_t st);
+hipError_t launch_gather_rows(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int n_tok, int8_t* xq, float* xs, hipStream_t st, int xs_ld = 0);
 hipError_t launch_scatter_rows(const char* blocks, size_t blk_stride, int world, int n_l, int n_tok, float* dst, int add, hipStream_t st);
 hipError_t launch_rmsnorm(const float* x, const float* w, float* o, int n, float eps, int add_unit, hipStream_t st);
 hipError_t launch_softmax(float* x, int n, hipStream_t st);
@@ -176,6 +176,10 @@ struct GemmArgs {
     float* out;                          // STORE / RESID: [n_tok][o]; SWIGLU: [n_tok][o/2]; QKV: q [n_tok][att_dim]
     float* k_raw; float* v_cache; int att_dim, kv_dim, seq_len, layer, pos0;    // EPI_QKV
     const float* bias; const float* resid; float qscale;                         // CLIP epilogues: bias [o], residual [n_tok][o], sqrt(head_size)
+    // Scale layouts of the ring kernels (round 6): 0 = [row][n/128] as everywhere else; ld > 0 = TRANSPOSED, the scale of (row, group g) at base[g * ld + row] -
+    // a group's scales of 64 rows are then 256 consecutive bytes, two cache lines, instead of 64 lines (a row's line holds 32 groups' scales of ONE row).
+    // ws_ld: weights (the library keeps a transposed copy of the layers' scales for the batched path); xs_ld / hs_ld: activations in / quantised h out.
+    int ws_ld, xs_ld, hs_ld;
     int8_t* hq; float* hs;                                                       // EPI_SWIGLU_Q / EPI_GELU_Q: quantised h [n_tok][o/2] int8 + scales [n_tok][o/256]
 };
 bool gemm_q8_hq_fused(int n, int o, int n_tok, bool q4);                         // host only: this w1/w3 launch can take the quantising epilogue
@@ -185,7 +189,8 @@ GemmTile gemm_q8_ring_tile(int n, int o, int n_tok, bool q4);                   
 hipError_t launch_matmul_f32_rows(const GemmArgs& a, int epi, hipStream_t s);   // q_type None sections of the image path (lmrs_f32.inc)
 bool rows_prologue_supported(int n);
 hipError_t launch_rows_prologue(float* x, const float* rms_w, const float* delta, const float* add_w, float eps, int add_unit, int mode, int q4,
-                                int n, int n_tok, int8_t* xq, float* xs, hipStream_t s);
+                                int n, int n_tok, int8_t* xq, float* xs, hipStream_t s, int xs_ld = 0);      // xs_ld > 0: scales transposed, (token, group) at xs[g * xs_ld + token]
+hipError_t launch_transpose_scales(const float* ws, int rows, int groups, float* wsT, hipStream_t s);          // wsT[g * rows + r] = ws[r * groups + g]
 hipError_t launch_rows_addnorm(float* x, const float* delta, const float* w, float eps, int n, int n_tok, hipStream_t s);
 hipError_t launch_rope_rows(float* q, const float* k_raw, float* k_cache, const float* rope, int n_heads, int n_kv_heads, int hs, int seq_len,
                             int layer, int pos0, int n_tok, hipStream_t s);

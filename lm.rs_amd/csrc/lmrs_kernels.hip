@@ -3168,7 +3168,7 @@ hipError_t launch_quantize_rows(const float* x, int n, int n_tok, int q4, int8_t
 }
 // ... and the gathered blocks of all shards ([w]: n_tok x n_l int8, then at s_off n_tok x n_l / 128 scales) as the activation operand of the
 // GEMM that follows: xq [n_tok][world * n_l], xs [n_tok][world * n_l / 128].  One workgroup per token; 16 bytes per lane.
-__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int8_t* xq, float* xs) {
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int8_t* xq, float* xs, int xs_ld) {
     const size_t t = blockIdx.x;
     const int n = world * n_l, gl = n_l / kGS;
     for (int e = threadIdx.x * 16; e < n; e += kBlock * 16) {
@@ -3177,12 +3177,26 @@ __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const char* blocks,
     }
     for (int g = threadIdx.x; g < n / kGS; g += kBlock) {
         const int w = g / gl, j = g - w * gl;
-        xs[t * (n / kGS) + g] = __builtin_nontemporal_load(reinterpret_cast<const float*>(blocks + (size_t)w * blk_stride + s_off) + t * gl + j);
+        const float v = __builtin_nontemporal_load(reinterpret_cast<const float*>(blocks + (size_t)w * blk_stride + s_off) + t * gl + j);
+        if (xs_ld) xs[(size_t)g * xs_ld + t] = v; else xs[t * (n / kGS) + g] = v;
     }
 }
-hipError_t launch_gather_rows(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int n_tok, int8_t* xq, float* xs, hipStream_t st) {
+hipError_t launch_gather_rows(const char* blocks, size_t blk_stride, size_t s_off, int world, int n_l, int n_tok, int8_t* xq, float* xs, hipStream_t st, int xs_ld) {
     if (n_l % kGS || s_off % 16 || blk_stride % 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_tok), dim3(kBlock), 0, st, blocks, blk_stride, s_off, world, n_l, xq, xs);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_tok), dim3(kBlock), 0, st, blocks, blk_stride, s_off, world, n_l, xq, xs, xs_ld);
+    return hipGetLastError();
+}
+
+// wsT[g * rows + r] = ws[r * groups + g]: the layers' weight scales, once at create, for the ring GEMMs of the batched path (GemmArgs::ws_ld)
+__global__ __launch_bounds__(kBlock) void transpose_scales_kernel(const float* __restrict__ ws, int rows, int groups, float* __restrict__ wsT) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, g0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
+    for (int k = ty; k < 32; k += 8) { const int r = r0 + k, g = g0 + tx; tile[k][tx] = r < rows && g < groups ? ws[(size_t)r * groups + g] : 0.0f; }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) { const int g = g0 + k, r = r0 + tx; if (g < groups && r < rows) wsT[(size_t)g * rows + r] = tile[tx][k]; }
+}
+hipError_t launch_transpose_scales(const float* ws, int rows, int groups, float* wsT, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_scales_kernel, dim3((rows + 31) / 32, (groups + 31) / 32), dim3(kBlock), 0, s, ws, rows, groups, wsT);
     return hipGetLastError();
 }
 

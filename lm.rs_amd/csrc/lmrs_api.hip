@@ -1994,11 +1994,13 @@ extern "C" int lmrs_op_expf(int device, float* y, const float* x, size_t n) {
 struct VisLayer {
     float *ln1 = nullptr, *ln1_b = nullptr, *ln2 = nullptr, *ln2_b = nullptr, *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     char *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr; float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // weights: int8 / packed nibbles / f32; scales (quantised only)
+    float *sqkvT = nullptr, *soT = nullptr, *s1T = nullptr, *s2T = nullptr;            // the scales transposed, [group][row] (made at the first forward: GemmArgs::ws_ld)
 };
 struct lmrs_vision {
     int device = 0; hipStream_t stream = nullptr;
     uint32_t dim = 0, hidden = 0, n_layers = 0, n_heads = 0, head_size = 0, patch = 0, image = 0, gs = 0; float eps = 0;
     int qt = LMRS_Q8_0;                            // q_type of the section: Q8_0, Q4_0 or None (f32)
+    bool no_scales_t = false;                      // the transposed scale copies could not be allocated: row-major scales stay in use
     float *class_emb = nullptr, *patch_emb = nullptr, *pos_emb = nullptr, *pre_ln = nullptr, *pre_ln_b = nullptr;
     std::vector<VisLayer> layers;
     std::vector<void*> owned;
@@ -2134,11 +2136,28 @@ extern "C" int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, ui
     // One projection of the whole batch: quantise the rows with the section's quantiser (Q8_0: fused into the layernorm where
     // there is one; Q4_0: rows_prologue_kernel's Q4 flavour) and run the int8-MFMA GEMM, or the f32 matmul kernel (q_type None).
     // src_f32: the rows [n_tok][n] (for Q8_0 with pre_quantised = true they are already in xq / xs).
-    auto project = [&](const float* src_f32, bool pre_quantised, const char* w, const float* ws, int n, int o, GemmArgs g, int epi) -> int {
+    // scale layouts (round 6): the ring GEMMs of a batch of >= 48 rows take TRANSPOSED scales - the layers' copies are made here, once; the activation scales
+    // are written that way by the layernorm / quantise rows (leading dimension n_tok)
+    if (v->qt == LMRS_Q8_0 && !v->layers.empty() && !v->layers[0].sqkvT && !v->no_scales_t) {      // (Q4_0 sections run the direct kernels: row-major scales)
+        bool ok = true;
+        auto tr = [&](const float* src, int rows, int groups) -> float* {
+            float* d = nullptr;
+            if (!ok || hipMalloc(reinterpret_cast<void**>(&d), (size_t)rows * groups * 4) != hipSuccess) { (void)hipGetLastError(); ok = false; return nullptr; }
+            v->owned.push_back(d);
+            if (launch_transpose_scales(src, rows, groups, d, s) != hipSuccess) ok = false;
+            return d;
+        };
+        for (VisLayer& Y : v->layers) { Y.sqkvT = tr(Y.sqkv, 3 * dim, dim / 128); Y.soT = tr(Y.so, dim, dim / 128); Y.s1T = tr(Y.s1, hid, dim / 128); Y.s2T = tr(Y.s2, dim, hid / 128); }
+        if (!ok) { for (VisLayer& Y : v->layers) Y.sqkvT = Y.soT = Y.s1T = Y.s2T = nullptr; v->no_scales_t = true; }
+    }
+    const bool trs = n_tok >= 48 && v->qt == LMRS_Q8_0 && v->layers[0].sqkvT != nullptr;
+    const int xld = trs ? n_tok : 0;
+    auto project = [&](const float* src_f32, bool pre_quantised, const char* w, const float* ws, const float* wsT, int n, int o, GemmArgs g, int epi) -> int {
         g.wq = w; g.ws = ws; g.n = n; g.o = o; g.n_tok = n_tok;
         if (v->qt == LMRS_Q_NONE) { g.xf = src_f32; HIP_OK(launch_matmul_f32_rows(g, epi, s)); return 0; }
-        if (!pre_quantised) HIP_OK(launch_rows_prologue(const_cast<float*>(src_f32), nullptr, nullptr, nullptr, 0.f, 0, 0, v->qt == LMRS_Q4_0, n, n_tok, v->xq, v->xs, s));
+        if (!pre_quantised) HIP_OK(launch_rows_prologue(const_cast<float*>(src_f32), nullptr, nullptr, nullptr, 0.f, 0, 0, v->qt == LMRS_Q4_0, n, n_tok, v->xq, v->xs, s, xld));
         g.xq = v->xq; g.xs = v->xs; g.q4 = v->qt == LMRS_Q4_0;
+        if (trs) { g.ws = wsT; g.ws_ld = o; g.xs_ld = xld; }
         HIP_OK(launch_gemm_q8(g, epi, s));
         return 0;
     };
@@ -2146,18 +2165,18 @@ extern "C" int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, ui
     for (uint32_t l = 0; l + 1 < v->n_layers; ++l) {                      // the penultimate layer's output is used (:303)
         const VisLayer& Y = v->layers[l];
         // layernorm 1 (Q8_0: quantised in the same launch; otherwise f32 rows into AO, which is free until the attention writes it)
-        HIP_OK(launch_vis_layernorm(v->X, Y.ln1, Y.ln1_b, v->eps, dim, n_tok, q8 ? nullptr : v->AO, v->xq, v->xs, s));
+        HIP_OK(launch_vis_layernorm(v->X, Y.ln1, Y.ln1_b, v->eps, dim, n_tok, q8 ? nullptr : v->AO, v->xq, v->xs, s, xld));
         GemmArgs g{};
         g.out = v->QKV; g.bias = Y.bqkv; g.att_dim = dim; g.qscale = sqrtf((float)v->head_size);
-        if (project(v->AO, q8, Y.wqkv, Y.sqkv, dim, 3 * dim, g, EPI_VQKV)) return -1;
+        if (project(v->AO, q8, Y.wqkv, Y.sqkv, Y.sqkvT, dim, 3 * dim, g, EPI_VQKV)) return -1;
         HIP_OK(launch_vis_attention(v->QKV, v->AO, v->scratch, (int)num_crops, (int)v->n_heads, T, dim, s));
         g = GemmArgs{}; g.out = v->E; g.bias = Y.bo; g.resid = v->X;
-        if (project(v->AO, false, Y.wo, Y.so, dim, dim, g, EPI_BIAS_RESID)) return -1;
-        HIP_OK(launch_vis_layernorm(v->E, Y.ln2, Y.ln2_b, v->eps, dim, n_tok, q8 ? nullptr : v->AO, v->xq, v->xs, s));
+        if (project(v->AO, false, Y.wo, Y.so, Y.soT, dim, dim, g, EPI_BIAS_RESID)) return -1;
+        HIP_OK(launch_vis_layernorm(v->E, Y.ln2, Y.ln2_b, v->eps, dim, n_tok, q8 ? nullptr : v->AO, v->xq, v->xs, s, xld));
         g = GemmArgs{}; g.out = v->H; g.bias = Y.b1;
-        if (project(v->AO, q8, Y.w1, Y.s1, dim, hid, g, EPI_BIAS_QGELU)) return -1;
+        if (project(v->AO, q8, Y.w1, Y.s1, Y.s1T, dim, hid, g, EPI_BIAS_QGELU)) return -1;
         g = GemmArgs{}; g.out = v->X; g.bias = Y.b2; g.resid = v->E;
-        if (project(v->H, false, Y.w2, Y.s2, hid, dim, g, EPI_BIAS_RESID)) return -1;
+        if (project(v->H, false, Y.w2, Y.s2, Y.s2T, hid, dim, g, EPI_BIAS_RESID)) return -1;
     }
     for (uint32_t c = 0; c < num_crops; ++c)                               // drop the CLS embedding (:571-579)
         HIP_OK(hipMemcpyAsync(out + (size_t)c * 576 * dim, v->X + ((size_t)c * T + 1) * dim, (size_t)576 * dim * 4, hipMemcpyDeviceToHost, s));

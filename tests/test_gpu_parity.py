@@ -420,6 +420,7 @@ def test_w13_with_the_quantiser_of_h_in_its_epilogue(L, n, o, sl, gemma):
 
 @pytest.mark.parametrize("cfg,q,n_tok,pos0", [("mini-llama", S.Q8_0, 70, 5), ("mini-llama3b", S.Q8_0, 33, 0), ("mini-phi", S.Q8_0, 140, 2),
                                               ("mini-llama-long", S.Q8_0, 600, 3), ("mini-llama", S.Q4_0, 70, 5), ("mini-gemma", S.Q8_0, 50, 3),
+                                              ("mini-llama-long", S.Q8_0, 530, 0),     # a 512-token pass on the ring kernels (transposed scales), then 18 tokens on the direct ones (row-major)
                                               ("mini-gemma", S.Q4_0, 75, 0),
                                               # 48 <= tokens < 64: the LDS-DMA ring GEMM's smallest batches (one ragged token tile)
                                               ("mini-llama", S.Q8_0, 48, 1), ("mini-llama3b", S.Q8_0, 57, 0), ("mini-phi", S.Q8_0, 63, 2)])

@@ -1,3 +1,4 @@
+# Round 6, one GPU call: Gemma / Q4_0 parity tests, Gemma-2-2B Q4_0 fill_kv_cache at 512 / 256 / 128 tokens, rocprofv3 kernel statistics of the 256-token fill.
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r6; mkdir -p $O
 {
 echo "== parity"; timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "matmul_q8_token_batch or fill_kv_cache or batched or gemma or random_geometries or q4" 2>&1 | tail -3

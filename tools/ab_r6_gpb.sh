@@ -1,3 +1,5 @@
+# Round 6, one GPU call: parity + fill_kv_cache under LMRS_GEMM_GPB = 1 / 2 / 4 (groups per barrier) -> profiles/r6_ab_gemm_structure.txt (1).
+# The switch exists only in tools/ubench/r6_gemm_gpb_and_column.patch (the form measured no faster and left the library); kept as the record of how the numbers were taken.
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r6; mkdir -p $O
 {
 for g in 2 4; do

@@ -1,3 +1,4 @@
+# Round 6, same-box A/B of library builds (make -C lm.rs_amd/csrc V=name EXTRA=-D...) on decode step time by position -> profiles/r6_ab_long_decode.txt.   usage: ab_r6_long.sh name...
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r6; mkdir -p $O
 for n in base "$@"; do
   L=$PWD/lm.rs_amd/liblmrs_hip_$n.so; [ $n = base ] && L=$PWD/lm.rs_amd/liblmrs_hip.so

@@ -1,3 +1,5 @@
+# Round 6, one GPU call: the batched-prefill parity tests, then fill_kv_cache of the four models with / without the two launch fusions
+# (LMRS_NO_PREFILL_FUSION=1, a context flag) -> profiles/r6_ab_prefill_fusion.txt.  (LMRS_Q4_WAVE_COLUMN was the build's A/B switch for the Q4_0 wave columns, adopted since.)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r6; mkdir -p $O
 {
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "w13_with or fill_kv_cache or batched or prefill or full_size or gemma_2b or random_geometries or multimodal_prefill" 2>&1 | tail -5

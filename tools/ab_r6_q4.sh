@@ -1,3 +1,4 @@
+# Round 6, one GPU call: Q4_0 / Gemma parity tests and the Q4_0 fill_kv_cache sweep of profiles/r6_ab_q4_pair_tiles.txt (3).
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r6; mkdir -p $O
 {
 echo "== parity"; timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "q4 or gemma or fill_kv_cache or batched or random_geometries or vision or projector or multimodal" 2>&1 | grep -E "passed|failed" | tail -2

@@ -1,3 +1,4 @@
+# Round 6, one GPU call: GEMM parity tests + fill_kv_cache of the models + the CLIP tower on the current build (used after each GEMM change).
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r6; mkdir -p $O
 {
 echo "== parity"; timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "matmul_q8_token_batch or fill_kv_cache_batched or w13_with or random_geometries or vision_tower" 2>&1 | tail -3

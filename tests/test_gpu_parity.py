@@ -1105,6 +1105,20 @@ def test_vision_tower_matches_the_cpu_path(L, n_layers, num_crops):
     assert_bit_equal(got.reshape(-1), ref.reshape(-1), f"vision tower, {n_layers - 1} layer(s), {num_crops} crop(s)")
 
 
+def test_vision_tower_with_the_last_query_in_a_block_of_its_own(L, monkeypatch):
+    """577 = 9 x 64 + 1: query 576 is normally taken by workgroups of its own inside the softmax launch (vis_att_stray: threads = keys, then (lane sum, dim)
+    pairs).  LMRS_VIS_NO_STRAY=1 runs it as a tenth block with one live lane through the blocked phases instead: both forms equal the CPU path bit for bit."""
+    from tools import synth_vision as V
+    cfg = V.VisionCfg(n_layers=2)
+    sec = V.build_vision_section(cfg, seed=77)
+    dev = L.VisionTransformer(sec); orc = O.VisionOracle(sec)
+    pv = V.pixel_values(cfg, 2, seed=6)
+    ref = orc.forward(pv, 2)
+    assert_bit_equal(dev.forward(pv, 2).reshape(-1), ref.reshape(-1), "vision tower, stray query in its own workgroups")
+    monkeypatch.setenv("LMRS_VIS_NO_STRAY", "1")
+    assert_bit_equal(dev.forward(pv, 2).reshape(-1), ref.reshape(-1), "vision tower, last query as a tenth block")
+
+
 @pytest.mark.parametrize("q,n_layers,num_crops", [(S.Q4_0, 3, 2), (S.Q_NONE, 2, 1), (S.Q_NONE, 3, 2)])
 def test_vision_tower_with_q4_and_unquantised_sections(L, q, n_layers, num_crops):
     """The other two section types export.py writes for the tower (vision.rs:110-243): Q4_0 - quantize_q4 of every row, matmul_q4 on

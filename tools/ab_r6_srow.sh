@@ -1,5 +1,5 @@
 #!/bin/bash
-# batched attention's value phase: LDS-fed (att_values_kernel) against scalar-fed rows (LMRS_ATT_VALUES_SROW=1)
+# batched attention value phase: LDS-fed (att_values_kernel) against scalar-fed rows (LMRS_ATT_VALUES_SROW=1; needs tools/ubench/r6_att_values_srow.patch applied - the form is not in the library)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; export LMRS_BENCH_IMAGE_CACHE=/tmp
 mkdir -p gpurun_out/r6; O=gpurun_out/r6/ab_srow.txt; : > $O
 echo "== parity, LMRS_ATT_VALUES_SROW=1 (fill_kv_cache / prefill / multimodal tests)" >> $O

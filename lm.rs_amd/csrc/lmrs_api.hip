@@ -2001,6 +2001,7 @@ struct lmrs_vision {
     uint32_t dim = 0, hidden = 0, n_layers = 0, n_heads = 0, head_size = 0, patch = 0, image = 0, gs = 0; float eps = 0;
     int qt = LMRS_Q8_0;                            // q_type of the section: Q8_0, Q4_0 or None (f32)
     bool no_scales_t = false;                      // the transposed scale copies could not be allocated: row-major scales stay in use
+    bool no_stray = false;                         // LMRS_VIS_NO_STRAY, read once at create: the 577th query as a tenth block of 64 lanes (A/B aid, tests)
     float *class_emb = nullptr, *patch_emb = nullptr, *pos_emb = nullptr, *pre_ln = nullptr, *pre_ln_b = nullptr;
     std::vector<VisLayer> layers;
     std::vector<void*> owned;
@@ -2034,6 +2035,7 @@ extern "C" int lmrs_vision_create(const uint8_t* sec, size_t len, int device, lm
     if (op_begin(device)) return -1;
     if (len < 128) return fail("vision section shorter than its 128-byte header");
     lmrs_vision* v = new lmrs_vision();
+    v->no_stray = getenv("LMRS_VIS_NO_STRAY") != nullptr;
     v->device = device;
     v->dim = rd32(sec); v->hidden = rd32(sec + 4); v->n_layers = rd32(sec + 8); v->n_heads = rd32(sec + 12); v->head_size = rd32(sec + 16);
     memcpy(&v->eps, sec + 20, 4); v->patch = rd32(sec + 24); v->image = rd32(sec + 28);
@@ -2169,7 +2171,7 @@ extern "C" int lmrs_vision_forward(lmrs_vision* v, const float* pixel_values, ui
         GemmArgs g{};
         g.out = v->QKV; g.bias = Y.bqkv; g.att_dim = dim; g.qscale = sqrtf((float)v->head_size);
         if (project(v->AO, q8, Y.wqkv, Y.sqkv, Y.sqkvT, dim, 3 * dim, g, EPI_VQKV)) return -1;
-        HIP_OK(launch_vis_attention(v->QKV, v->AO, v->scratch, (int)num_crops, (int)v->n_heads, T, dim, s));
+        HIP_OK(launch_vis_attention(v->QKV, v->AO, v->scratch, (int)num_crops, (int)v->n_heads, T, dim, !v->no_stray, s));
         g = GemmArgs{}; g.out = v->E; g.bias = Y.bo; g.resid = v->X;
         if (project(v->AO, false, Y.wo, Y.so, Y.soT, dim, dim, g, EPI_BIAS_RESID)) return -1;
         HIP_OK(launch_vis_layernorm(v->E, Y.ln2, Y.ln2_b, v->eps, dim, n_tok, q8 ? nullptr : v->AO, v->xq, v->xs, s, xld));

@@ -205,7 +205,7 @@ struct VisPatchArgs { const float* pixels; const float* kernel; const float* cla
 hipError_t launch_vis_patch_embed(const VisPatchArgs& a, int num_crops, hipStream_t s);
 // layernorm rows (functional.rs:80-114): out_f32 != null: f32 result; xq/xs != null: quantised result (Q8_0)
 hipError_t launch_vis_layernorm(const float* x, const float* w, const float* b, float eps, int dim, int n_tok, float* out_f32, int8_t* xq, float* xs, hipStream_t s, int xs_ld = 0);
-hipError_t launch_vis_attention(const float* qkv, float* out, float* scratch, int num_crops, int n_heads, int T, int dim, hipStream_t s);
+hipError_t launch_vis_attention(const float* qkv, float* out, float* scratch, int num_crops, int n_heads, int T, int dim, bool stray_workgroups, hipStream_t s);
 size_t vis_attention_scratch_floats(int num_crops, int n_heads, int T);
 hipError_t launch_vis_att_scores(const float* qkv, float* scratch, int num_crops, int n_heads, int nqb, int T, int dim, hipStream_t s);   // (a phase of launch_vis_attention)
 

@@ -263,10 +263,10 @@ __global__ __launch_bounds__(64 * NW) void vis_att_tree_kernel(const float* __re
     }
 }
 
-hipError_t launch_vis_attention(const float* qkv, float* out, float* scratch, int num_crops, int n_heads, int T, int dim, hipStream_t s) {
+hipError_t launch_vis_attention(const float* qkv, float* out, float* scratch, int num_crops, int n_heads, int T, int dim, bool stray_workgroups, hipStream_t s) {
     if (dim != n_heads * kVisHS || T < 64) return hipErrorInvalidValue;
     // one launch per phase, wave-granular grids (round 4: 7.5 -> 6.9 ms for the tower against the single-launch forms, which are gone from the library)
-    const bool no_stray = getenv("LMRS_VIS_NO_STRAY") != nullptr;              // (A/B and tests: the last block with its dead lanes, as before round 6; read at every call)
+    const bool no_stray = !stray_workgroups;                                   // (LMRS_VIS_NO_STRAY at lmrs_vision_create - A/B and tests: the last block with its dead lanes, as before round 6)
     const int rem = T % kVisQB, n_stray = (!no_stray && rem && rem <= kVisStrayMax && T <= kVisStrayT) ? rem : 0;      // vis_att_stray
     const int nqb = (T - n_stray + kVisQB - 1) / kVisQB;
     if (const hipError_t e = launch_vis_att_scores(qkv, scratch, num_crops, n_heads, nqb, T, dim, s)) return e;     // (lmrs_vision.inc: that kernel gains from the max-ilp strategy, 58.7 -> 51.5 us)

@@ -91,6 +91,8 @@ struct lmrs_ctx {
     bool no_batched_prefill = false;               // LMRS_NO_BATCHED_PREFILL=1 (read ONCE, at create): fill_kv_cache and prompts go token by token through the decode kernels
     bool no_fused_rope = false, no_fused_hq = false; // LMRS_NO_PREFILL_FUSION=1 (read at create; A/B aid): the batched prefill with RoPE and the h quantiser as launches of their own
     int att_dim = 0, kv_dim = 0, cls_grid = 0;     // att_dim / kv_dim: THIS shard's query / key-value widths
+    int part_stride = 0;                           // floats between two shards' argmax partials: 2 * cls_grid rounded up to 16 bytes (the push transport copies 16 bytes per lane;
+                                                   // Llama-3.2-1B on 8 shards has 501 partials per shard)
     bool q4 = false, f32 = false;                  // f32: q_type None (unquantised weights, lmrs_f32.inc)
     // ---- row sharding.  Every shard owns whole output rows, so every float accumulation chain
     // lives on one GPU and results are bit-identical to world == 1.
@@ -335,8 +337,8 @@ GemvArgs cls_args(lmrs_ctx* c) {
     g.n = a.dim; g.o = cls_rows(c); g.xin = c->x; g.rms_w = c->rms_final; g.row_offset = c->v0;
     g.out = c->logits + c->v0;
     if (c->world > 1 || c->comm) {          // sharded: this shard's [values | indices] block of the gathered partials
-        g.part_val = c->part + (size_t)c->rank * 2 * c->cls_grid;
-        g.part_idx = reinterpret_cast<int*>(c->part + (size_t)c->rank * 2 * c->cls_grid) + c->cls_grid;
+        g.part_val = c->part + (size_t)c->rank * c->part_stride;
+        g.part_idx = reinterpret_cast<int*>(c->part + (size_t)c->rank * c->part_stride) + c->cls_grid;
         if (c->p2p && !getenv("LMRS_SHARD_SINGLE_PARTIALS")) { g.part_par = c->xseq + c->ex_slot; g.part_par_floats = (int)((size_t)c->world * 2 * kMaxArgmaxParts); }   // the exchange enqueued next takes this slot
     } else { g.part_val = c->part_val; g.part_idx = c->part_idx; }
     g.softcap_rows = a.model_type == LMRS_GEMMA ? (int)a.dim : 0;
@@ -427,7 +429,7 @@ ExchangeDesc exchange_after(lmrs_ctx* c, int seg) {
         }
     }
     if (seg == L4) {                                             // peer-to-peer: the partials are double-buffered (ArgmaxArgs::part_par)
-        ExchangeDesc e = f32s(c->part, (size_t)2 * c->cls_grid);
+        ExchangeDesc e = f32s(c->part, (size_t)c->part_stride);
         if (part_double(c)) e.par = part_half_floats(c) * 4;
         return e;
     }
@@ -516,7 +518,7 @@ int run_segment(lmrs_ctx* c, int seg) {
     set_launch_tag(6);
     ArgmaxArgs m{};
     m.part_val = c->part; m.part_idx = reinterpret_cast<const int*>(c->part) + c->cls_grid; m.n_part = c->cls_grid;
-    m.n_groups = c->world; m.group_stride = 2 * c->cls_grid;
+    m.n_groups = c->world; m.group_stride = c->part_stride;
     if (part_double(c) && c->ex_slot > 0) { m.part_par = c->xseq + (c->ex_slot - 1); m.part_par_floats = (int)part_half_floats(c); }     // the slot of the partials exchange just enqueued
     m.logits = c->logits; m.tokens = c->tokens; m.st = c->st; m.seq = c->seq; m.emb = embed_args(c); m.tail_row = unwritten_tail(c);
     HIP_OK(launch_argmax_final(m, c->stream));
@@ -1039,6 +1041,7 @@ static int create_impl(const uint8_t* file, size_t len, int device, int rank, in
     {
         GemvArgs g = cls_args(c);
         c->cls_grid = f32w ? gemv_f32_grid(g, EPI_CLS) : gemv_grid(g, c->gemma_fused ? PRO_ADD_RMS_QUANT : PRO_RMS_QUANT, EPI_CLS);
+        c->part_stride = (2 * c->cls_grid + 3) & ~3;
     }
     // (also the "cls" shard plan in its one-process-per-GPU form: there every GPU runs the layers whole, with the single-GPU launches)
     if ((!sharded || (cls_only && !group_mode)) && !f32w && !(getenv("LMRS_QKV_ATT") && atoi(getenv("LMRS_QKV_ATT")) == 0)) {

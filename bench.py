@@ -561,8 +561,16 @@ def main():
             finally:
                 os.environ.pop("LMRS_SHARD_SPLIT_OUT", None)
 
-        out = headline_then_guarded(headline, [("library_choice", library_choice), ("tp_split_out", tp_split_out)], barrier, rank,
-                                    float(os.environ.get("LMRS_BENCH_LIBRARY_CHOICE_TIMEOUT", "240")))
+        if any(v % world for v in (cfg.n_kv_heads, cfg.dim, cfg.hidden_dim, cfg.vocab_size)):
+            # the row split north_star names does not exist for this model on this many GPUs (Gemma-2-2B's 4 kv heads on 8): the one configuration
+            # there is - whole layers on every GPU, the classifier's rows split (plan "cls"; it needs world | vocab_size) - is the line then, and says so
+            out = run_once(plan="cls", transport_override=None if one_dev else os.environ.get("LMRS_BENCH_TRANSPORT"), emit=False)
+            if rank == 0 and out is not None:
+                out["headline_is"] = f"plan cls: {world} does not divide this model's n_kv_heads / dim / hidden_dim, plan tp does not exist"
+                print(json.dumps(out), flush=True)
+        else:
+            out = headline_then_guarded(headline, [("library_choice", library_choice), ("tp_split_out", tp_split_out)], barrier, rank,
+                                        float(os.environ.get("LMRS_BENCH_LIBRARY_CHOICE_TIMEOUT", "240")))
     if dist is not None:
         dist.destroy_process_group()
     return out
